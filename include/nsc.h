@@ -1,0 +1,101 @@
+/*
+ * nsc.h -- C ABI of libnsc_hip.so, the MI355X (gfx950) implementation of the Neural-Spectral-Codec
+ * descriptor hot path.
+ *
+ * The reference is pure Python and has no FFI layer; its boundary for this path is two nn.Module
+ * APIs.  Each entry point below replaces the device work behind one of those
+ * calls; the Python classes in neural-spectral-codec_amd/{encoding,gnn}/ keep the reference's
+ * names and signatures and bind these functions with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (e.g. torch tensor storage);
+ *     parameter structs are HOST pointers, read before the call returns
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing,
+ *     keeps no mutable global state and is safe to capture into a hipGraph
+ *   - return value: 0 = NSC_OK, negative = NscStatus error; nothing is launched on error
+ *   - no torch types, no C++ types, no exceptions across the boundary
+ */
+#ifndef NSC_H
+#define NSC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSC_ABI_VERSION 1
+
+typedef enum NscStatus {
+    NSC_OK            = 0,
+    NSC_EINVAL        = -1,  /* null pointer / negative size / inconsistent arguments          */
+    NSC_EUNSUPPORTED  = -2,  /* shape outside what the kernels are built for (see each call)   */
+    NSC_EWORKSPACE    = -3,  /* workspace smaller than nsc_*_workspace_bytes()                  */
+    NSC_ELAUNCH       = -4   /* hipLaunchKernel reported an error (hipGetLastError has details) */
+} NscStatus;
+
+int         nsc_abi_version(void);
+const char *nsc_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder: point cloud -> E x 360 min-range image -> circular gap interpolation -> row-wise
+ * 360-point real FFT magnitude -> per-row 181->n_bins histogram -> global L1 normalisation.
+ * Replaces SpectralEncoder.encode_points / encode_range_image / forward
+ *   (reference src/encoding/spectral_encoder.py:206, :160, :231) and what they call:
+ *   RangeImageProjector.project (src/encoding/range_image.py:129) and
+ *   interpolate_range_image    (src/encoding/range_image.py:15).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct NscEncParams {
+    int32_t n_elevation;   /* projector rows E: 1..64          range_image.py:104              */
+    int32_t n_azimuth;     /* projector cols A: must be 360    range_image.py:105              */
+    int32_t n_bins;        /* histogram bins per row, 1..181   spectral_encoder.py:39          */
+    int32_t target_rows;   /* target_elevation_bins R, 1..16   spectral_encoder.py:43          */
+    double  elev_min_rad;  /* np.deg2rad(elevation_range[0])   range_image.py:126              */
+    double  elev_max_rad;  /* np.deg2rad(elevation_range[1])   range_image.py:127              */
+    float   min_range;     /* 1.0                              range_image.py:108              */
+    float   max_range;     /* 80.0                             range_image.py:107              */
+    float   epsilon;       /* 1e-8                             spectral_encoder.py:42          */
+    int32_t interpolate;   /* interpolate_empty                spectral_encoder.py:44,220      */
+    int32_t elev_f64;      /* 1 = row math in float64 (numpy >= 2 promotion of range_image.py:186),
+                              0 = float32 (numpy 1.24 value-based casting)                      */
+} NscEncParams;
+
+void nsc_enc_default_params(NscEncParams *p);
+
+/* Bytes of scratch nsc_encode_clouds needs for this batch (0 when the fused one-workgroup-per-
+ * cloud kernel is used; non-zero when clouds are split across workgroups). */
+size_t nsc_encode_clouds_workspace_bytes(int32_t n_clouds, int64_t total_points,
+                                         const NscEncParams *p);
+
+/* SpectralEncoder.encode_points for a packed batch of clouds.
+ *   pts            (total_points, stride) float32, row-major AoS [x,y,z(,intensity)]; stride 3 or 4
+ *   cloud_offsets  (n_clouds+1) int64 point offsets, cloud c = [off[c], off[c+1]); off[0] = 0
+ *   lut            (181) int32  frequency -> bin table (spectral_encoder.py:136-145), monotone
+ *   out_desc       (n_clouds, target_rows*n_bins) float32
+ *   out_raw        nullable (n_clouds, E, 360) float32  image before interpolation
+ *   out_interp     nullable (n_clouds, E, 360) float32  image after interpolation
+ *   ws, ws_bytes   scratch of at least nsc_encode_clouds_workspace_bytes() (may be NULL if 0) */
+int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_clouds,
+                      int64_t total_points, int32_t stride_floats, const NscEncParams *p,
+                      const int32_t *lut, float *out_desc, float *out_raw, float *out_interp,
+                      void *ws, size_t ws_bytes, void *stream);
+
+/* SpectralEncoder.forward / encode_range_image for a batch of range images (no projection, no
+ * interpolation; rows != target_rows are average-pooled like adaptive_avg_pool2d).
+ *   imgs      (n_images, rows, 360) float32, rows 1..64
+ *   out_desc  (n_images, target_rows*n_bins) float32 */
+int nsc_encode_range_images(const float *imgs, int32_t n_images, int32_t rows,
+                            const NscEncParams *p, const int32_t *lut, float *out_desc,
+                            void *stream);
+
+/* Parity triage: per point, the pixel index row*360+col the scatter uses (-1 = dropped) and
+ * whether the exact (float64 atan2) path decided it (bit0 azimuth, bit1 elevation). */
+int nsc_debug_point_bins(const float *pts, int64_t n_points, int32_t stride_floats,
+                         const NscEncParams *p, int32_t *out_idx, uint8_t *out_flags /*nullable*/,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSC_H */

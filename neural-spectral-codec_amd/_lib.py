@@ -1,0 +1,79 @@
+"""ctypes binding of csrc/libnsc_hip.so (include/nsc.h).  No fallback: if the library is missing
+or a call fails, this raises."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- loads torch's libamdhip64 first so the library shares its HIP runtime
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnsc_hip.so")
+
+
+class NscError(RuntimeError):
+    pass
+
+
+class EncParams(C.Structure):
+    """struct NscEncParams (include/nsc.h)"""
+    _fields_ = [
+        ("n_elevation", C.c_int32), ("n_azimuth", C.c_int32), ("n_bins", C.c_int32),
+        ("target_rows", C.c_int32), ("elev_min_rad", C.c_double), ("elev_max_rad", C.c_double),
+        ("min_range", C.c_float), ("max_range", C.c_float), ("epsilon", C.c_float),
+        ("interpolate", C.c_int32), ("elev_f64", C.c_int32),
+    ]
+
+
+_lib = None
+
+# every symbol include/nsc.h declares: (restype, argtypes)
+_vp, _i32, _i64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+_pp = C.POINTER(EncParams)
+SYMBOLS = {
+    "nsc_abi_version": (C.c_int, []),
+    "nsc_status_string": (C.c_char_p, [C.c_int]),
+    "nsc_enc_default_params": (None, [_pp]),
+    "nsc_encode_clouds_workspace_bytes": (_sz, [_i32, _i64, _pp]),
+    "nsc_encode_clouds": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_encode_range_images": (C.c_int, [_vp, _i32, _i32, _pp, _vp, _vp, _vp]),
+    "nsc_debug_point_bins": (C.c_int, [_vp, _i64, _i32, _pp, _vp, _vp, _vp]),
+}
+
+
+def lib():
+    """Load the HIP library (once).  Raises NscError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NscError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.nsc_abi_version() != 1:
+            raise NscError("libnsc_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().nsc_status_string(status).decode()
+        raise NscError(f"{what} failed: {msg} (status {status})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise NscError(f"{name} must live on a HIP device (got {t.device}); the MI355X path has no "
+                       "CPU fallback -- move the module/tensors to 'cuda'")

@@ -1,0 +1,230 @@
+// nsc_math.h -- per-point binning math shared by the HIP kernels and the host-side margin checks.
+//
+// The pixel a point lands in is DEFINED by the exact chain below (float32 ops of
+// RangeImageProjector.project, reference src/encoding/range_image.py:157-198, with atan2f taken
+// as the correctly rounded float32 result).  The kernels evaluate a cheap float32 estimate first
+// and accept it only when it is provably far from every bin edge; otherwise the exact chain runs.
+// Compile with -ffp-contract=off: nothing here may be contracted into an FMA behind our back.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NSC_HD __host__ __device__ inline
+#else
+#define NSC_HD inline
+#endif
+
+#define NSC_A 360                       /* azimuth columns (fixed: octant trick + 360-point FFT) */
+#define NSC_F 181                       /* rfft bins                                               */
+#define NSC_PI_F 3.1415927410125732f    /* float32(np.pi)    range_image.py:167                    */
+#define NSC_2PI_F 6.2831854820251465f   /* float32(2*np.pi)  range_image.py:167,195                */
+#define NSC_EMPTY_BITS 0xffffffffu      /* "no point yet" in the squared-range image               */
+
+struct NscBinParams {
+    double emin, espan;        // float64 elevation_min and (elevation_max - elevation_min)
+    float emin_f, espan_f;     // their float32 casts (numpy 1.24 float32 row math)
+    float el_scale;            // E / espan, float32, for the fast estimate
+    float az_delta, el_delta;  // acceptance margins of the fast estimate, in bin units
+    float s_lo, s_hi;          // range filter expressed on the squared range (see host code)
+    int E;                     // projector rows
+    int elev_f64;              // row math in float64 (numpy >= 2) or float32 (numpy 1.24)
+};
+
+// ---- exact chain ----------------------------------------------------------------------------
+
+NSC_HD float nsc_clip_sq(float v)
+{
+    float s = v * v;                    // range_image.py:159-161: np.clip(v**2, 0, 1e10), v finite
+    return s > 1e10f ? 1e10f : s;
+}
+
+NSC_HD float nsc_atan2f_cr(float y, float x)
+{
+    return (float)atan2((double)y, (double)x);
+}
+
+NSC_HD int nsc_col_from_angle(float a)  // a = atan2f_cr(y, x)            range_image.py:167,194-198
+{
+    a = a + NSC_PI_F;
+    if (a >= NSC_2PI_F) a = a - NSC_2PI_F;      // fmodf for 0 <= a <= 2*pi_f (exact subtraction)
+    float cf = a / NSC_2PI_F;
+    cf = cf * (float)NSC_A;
+    int col = (int)floorf(cf);
+    col = col < 0 ? 0 : col;
+    return col > NSC_A - 1 ? NSC_A - 1 : col;
+}
+
+NSC_HD int nsc_row_from_elev(float e, const NscBinParams &bp)           // range_image.py:186-191
+{
+    int row;
+    if (bp.elev_f64) {
+        double en = ((double)e - bp.emin) / bp.espan;
+        row = (int)floor(en * (double)bp.E);
+    } else {
+        float en = (e - bp.emin_f) / bp.espan_f;
+        row = (int)floorf(en * (float)bp.E);
+    }
+    row = row < 0 ? 0 : row;
+    return row > bp.E - 1 ? bp.E - 1 : row;
+}
+
+NSC_HD int nsc_col_exact(float y, float x) { return nsc_col_from_angle(nsc_atan2f_cr(y, x)); }
+
+NSC_HD int nsc_row_exact(float z, float sxy, const NscBinParams &bp)
+{
+    return nsc_row_from_elev(nsc_atan2f_cr(z, sqrtf(sxy)), bp);        // range_image.py:170-171
+}
+
+// ---- fast estimate --------------------------------------------------------------------------
+
+NSC_HD float nsc_rcp_approx(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);    // v_rcp_f32, 1 ULP
+#elif defined(NSC_TEST_APPROX_BIAS)  /* host margin tests: push the 1-ULP error to either side */
+    return nextafterf(1.0f / x, NSC_TEST_APPROX_BIAS > 0 ? INFINITY : 0.0f);
+#else
+    return 1.0f / x;
+#endif
+}
+
+NSC_HD float nsc_sqrt_approx(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);   // v_sqrt_f32, 1 ULP
+#elif defined(NSC_TEST_APPROX_BIAS)
+    return nextafterf(sqrtf(x), NSC_TEST_APPROX_BIAS > 0 ? 0.0f : INFINITY);
+#else
+    return sqrtf(x);
+#endif
+}
+
+// atan(t) for t in [0,1]: t * P(t^2), degree-8 minimax (5.8e-9 rad exact, < 1e-7 rad in float32)
+NSC_HD float nsc_atan01(float t)
+{
+    const float w = t * t;
+    float p = 2.4567242624e-03f;
+    p = __builtin_fmaf(p, w, -1.4401357072e-02f);
+    p = __builtin_fmaf(p, w, 3.9781223114e-02f);
+    p = __builtin_fmaf(p, w, -7.2348574340e-02f);
+    p = __builtin_fmaf(p, w, 1.0498946179e-01f);
+    p = __builtin_fmaf(p, w, -1.4161229249e-01f);
+    p = __builtin_fmaf(p, w, 1.9985906780e-01f);
+    p = __builtin_fmaf(p, w, -3.3332597030e-01f);
+    p = __builtin_fmaf(p, w, 9.9999988638e-01f);
+    return p * t;
+}
+
+// Column estimate.  Returns true when `col` is certain (estimate farther than az_delta from every
+// column edge); NaN estimates (x = y = 0) and exact octant boundaries come out uncertain.
+NSC_HD bool nsc_col_fast(float y, float x, float az_delta, int &col)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * nsc_rcp_approx(mx);
+    const float q = nsc_atan01(t) * 57.29577951308232f;   // columns inside the octant, [0,45]
+    const float fi = floorf(q);
+    const float f = q - fi;
+    const int iq = (int)fi;
+    int ib = (ax >= ay) ? iq : 89 - iq;                   // column of the first-quadrant angle
+    ib = (x < 0.0f) ? 179 - ib : ib;                      // angle from +x, [0,180)
+    col = (y < 0.0f) ? 179 - ib : 180 + ib;               // + pi shift of range_image.py:167
+    return (f > az_delta) && (f < 1.0f - az_delta);
+}
+
+// Row estimate; same contract.  Rows beyond the FOV clamp (range_image.py:187-191), so estimates
+// far outside [0,E] are certain too.
+NSC_HD bool nsc_row_fast(float z, float sxy, const NscBinParams &bp, int &row)
+{
+    const float rxy = nsc_sqrt_approx(sxy);
+    const float az = fabsf(z);
+    const float mx = fmaxf(az, rxy), mn = fminf(az, rxy);
+    const float t = mn * nsc_rcp_approx(mx);
+    float e = nsc_atan01(t);
+    e = (az > rxy) ? 1.5707963267948966f - e : e;
+    e = (z < 0.0f) ? -e : e;
+    const float u = (e - bp.emin_f) * bp.el_scale;
+    const float fi = floorf(u);
+    const float f = u - fi;
+    int r = (int)fminf(fmaxf(fi, 0.0f), (float)(bp.E - 1));
+    row = r;
+    const float d = bp.el_delta;
+    return ((f > d) && (f < 1.0f - d)) || (u < -d) || (u > (float)bp.E + d);
+}
+
+// ---- host-side setup (plain C++, also used by the CPU margin tests) ---------------------------
+// (host functions: hipcc's device pass parses but never emits them)
+
+// smallest float32 s >= 0 with pred(s) true, pred monotone false->true over non-negative floats
+template <class P> inline float nsc_first_true(P pred)
+{
+    uint32_t lo = 0u, hi = 0x7f800000u;          // +0 .. +inf bit patterns are ordered like floats
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2u;
+        float f;
+        __builtin_memcpy(&f, &mid, 4);
+        if (pred(f)) hi = mid; else lo = mid + 1u;
+    }
+    float f;
+    __builtin_memcpy(&f, &lo, 4);
+    return f;
+}
+
+// Largest distance (in columns) between an ideal column edge c*2pi/360 - pi and the float32
+// threshold at which the exact chain actually switches to column c.
+inline float nsc_az_edge_slack()
+{
+    static const float slack = [] {
+        double worst = 0.0;
+        for (int c = 1; c < NSC_A; ++c) {
+            // bisect over the ordered float32 angles in [-pi_f, pi_f)
+            auto key = [](float a) { uint32_t u; __builtin_memcpy(&u, &a, 4);
+                                     return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+            auto unkey = [](uint32_t k) { uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+                                          float a; __builtin_memcpy(&a, &u, 4); return a; };
+            uint32_t lo = key(-NSC_PI_F), hi = key(NSC_PI_F);
+            while (lo < hi) {
+                uint32_t mid = lo + (hi - lo) / 2u;
+                if (nsc_col_from_angle(unkey(mid)) >= c) hi = mid; else lo = mid + 1u;
+            }
+            const double thr = (double)unkey(lo);
+            const double ideal = -M_PI + (double)c * (2.0 * M_PI / NSC_A);
+            // thr is the first float32 angle in column c; the last one in column c-1 is one ULP
+            // below.  Both bracket where the exact chain switches.
+            const double below = (double)nextafterf((float)thr, -10.0f);
+            const double d1 = fabs(thr - ideal), d0 = fabs(below - ideal);
+            const double d = (d1 > d0 ? d1 : d0) * (NSC_A / (2.0 * M_PI));
+            if (d > worst) worst = d;
+        }
+        return (float)worst;
+    }();
+    return slack;
+}
+
+// Error budget of the float32 estimates (validated by tests/test_binning_margins.py on 1e8 points
+// and by the -m gpu debug-bin tests): v_rcp 1 ULP + polynomial + roundings, in bin units.
+#define NSC_AZ_EST_ERR 4.0e-5f
+#define NSC_EL_EST_ERR 3.0e-5f
+
+inline NscBinParams nsc_make_bin_params(int E, double emin, double emax, float rmin, float rmax,
+                                        int elev_f64)
+{
+    NscBinParams bp;
+    bp.emin = emin;
+    bp.espan = emax - emin;
+    bp.emin_f = (float)emin;
+    bp.espan_f = (float)bp.espan;
+    bp.el_scale = (float)((double)E / bp.espan);
+    bp.az_delta = nsc_az_edge_slack() + NSC_AZ_EST_ERR;
+    bp.el_delta = NSC_EL_EST_ERR;
+    bp.E = E;
+    bp.elev_f64 = elev_f64;
+    // range filter r >= rmin && r <= rmax with r = sqrtf(s) correctly rounded (monotone in s)
+    // (range_image.py:174): expressed on s so the kernels never take a per-point sqrt
+    bp.s_lo = nsc_first_true([&](float s) { return sqrtf(s) >= rmin; });
+    const float above = nsc_first_true([&](float s) { return sqrtf(s) > rmax; });
+    bp.s_hi = nextafterf(above, 0.0f);
+    return bp;
+}

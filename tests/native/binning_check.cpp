@@ -1,0 +1,62 @@
+// Host-side validation of the fast binning estimate's acceptance margins (test tool, built by
+// tests/test_binning_margins.py with g++).  For random points it compares the fast estimate,
+// when it claims certainty, with the exact chain of csrc/nsc_math.h.
+//   usage: binning_check N seed emin_deg emax_deg E elev_f64
+//   prints: n az_uncertain el_uncertain az_wrong el_wrong az_slack
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include "nsc_math.h"
+
+static uint64_t s[2];
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint64_t next() {
+    uint64_t s0 = s[0], s1 = s[1], r = s0 + s1;
+    s1 ^= s0; s[0] = rotl(s0, 24) ^ s1 ^ (s1 << 16); s[1] = rotl(s1, 37);
+    return r;
+}
+static inline double u01() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
+
+int main(int argc, char **argv)
+{
+    long n = argc > 1 ? atol(argv[1]) : 1000000;
+    s[0] = 0x9E3779B97F4A7C15ull ^ (argc > 2 ? strtoull(argv[2], 0, 10) : 1); s[1] = 0xD1B54A32D192ED03ull;
+    double emin = (argc > 3 ? atof(argv[3]) : -24.8) * M_PI / 180.0;
+    double emax = (argc > 4 ? atof(argv[4]) : 2.0) * M_PI / 180.0;
+    int E = argc > 5 ? atoi(argv[5]) : 16;
+    int f64 = argc > 6 ? atoi(argv[6]) : 1;
+    NscBinParams bp = nsc_make_bin_params(E, emin, emax, 1.0f, 80.0f, f64);
+    long azu = 0, elu = 0, azw = 0, elw = 0;
+    for (long i = 0; i < n; ++i) {
+        float x, y, z;
+        int mode = (int)(next() % 4);
+        if (mode == 0) {                       // spherical like the bench clouds
+            double az = (u01() * 2 - 1) * M_PI, el = (u01() * 100 - 50) * M_PI / 180, r = 0.5 + u01() * 89.5;
+            x = (float)(r * cos(el) * cos(az)); y = (float)(r * cos(el) * sin(az)); z = (float)(r * sin(el));
+        } else if (mode == 1) {                // uniform cube
+            x = (float)((u01() * 2 - 1) * 80); y = (float)((u01() * 2 - 1) * 80); z = (float)((u01() * 2 - 1) * 40);
+        } else if (mode == 2) {                // points sitting on/next to column and row edges
+            int c = (int)(next() % 360), rr = (int)(next() % (E + 1));
+            double az = -M_PI + c * (2 * M_PI / 360) + (u01() - 0.5) * 4e-6;
+            double el = emin + rr * (emax - emin) / E + (u01() - 0.5) * 4e-6, r = 1 + u01() * 70;
+            x = (float)(r * cos(el) * cos(az)); y = (float)(r * cos(el) * sin(az)); z = (float)(r * sin(el));
+        } else {                               // tiny / huge ratios, axis-aligned
+            double a = (u01() * 2 - 1) * 60, b = (u01() * 2 - 1) * 1e-4;
+            if (next() & 1) { x = (float)a; y = (float)b; } else { x = (float)b; y = (float)a; }
+            z = (float)((u01() * 2 - 1) * 30);
+            if ((next() % 16) == 0) y = 0.0f;
+            if ((next() % 16) == 0) x = -0.0f;
+        }
+        const float xs = nsc_clip_sq(x), ys = nsc_clip_sq(y), zs = nsc_clip_sq(z);
+        const float sxy = xs + ys, ss = sxy + zs;
+        if (!(ss >= bp.s_lo && ss <= bp.s_hi)) continue;
+        int cf, rf;
+        bool cok = nsc_col_fast(y, x, bp.az_delta, cf);
+        bool rok = nsc_row_fast(z, sxy, bp, rf);
+        if (!cok) ++azu; else if (cf != nsc_col_exact(y, x)) ++azw;
+        if (!rok) ++elu; else if (rf != nsc_row_exact(z, sxy, bp)) ++elw;
+    }
+    printf("%ld %ld %ld %ld %ld %.9g %.9g %.9g\n", n, azu, elu, azw, elw, (double)nsc_az_edge_slack(),
+           (double)bp.s_lo, (double)bp.s_hi);
+    return 0;
+}

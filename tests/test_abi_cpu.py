@@ -1,0 +1,80 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/nsc.h
+declares, validates arguments without a GPU, and the fast binning estimate never disagrees with
+the exact chain when it claims certainty."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "neural-spectral-codec_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from neural_spectral_codec_amd import build, _lib
+    build.build_hip()
+    return _lib.lib()
+
+
+def test_header_symbols_exported(lib):
+    from neural_spectral_codec_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nsc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nsc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/nsc.h but not exported"
+    assert declared == set(_lib.SYMBOLS), "ctypes binding out of sync with include/nsc.h"
+
+
+def test_argument_validation_without_gpu(lib):
+    from neural_spectral_codec_amd import _lib
+    p = _lib.EncParams()
+    lib.nsc_enc_default_params(C.byref(p))
+    assert (p.n_elevation, p.n_azimuth, p.n_bins, p.target_rows) == (16, 360, 50, 16)
+    assert abs(p.elev_min_rad - np.deg2rad(-24.8)) < 1e-15
+    assert lib.nsc_abi_version() == 1
+    # errors are reported before anything is launched
+    assert lib.nsc_encode_clouds(None, None, 1, 10, 4, p, None, None, None, None, None, 0, None) == -1
+    assert lib.nsc_encode_clouds(None, None, 0, 0, 4, p, None, None, None, None, None, 0, None) == 0
+    assert lib.nsc_encode_clouds(None, None, 1, 10, 5, p, None, None, None, None, None, 0, None) == -1
+    p.n_azimuth = 720
+    assert lib.nsc_encode_clouds(None, None, 1, 10, 4, p, None, None, None, None, None, 0, None) == -2
+    assert b"unsupported" in lib.nsc_status_string(-2)
+    p.n_azimuth = 360
+    # split-path workspace: small batches of big clouds need E*360*4 bytes per cloud, big batches none
+    assert lib.nsc_encode_clouds_workspace_bytes(4, 480000, p) == 4 * 16 * 360 * 4
+    assert lib.nsc_encode_clouds_workspace_bytes(1024, 1024 * 120000, p) == 0
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from neural_spectral_codec_amd import _lib
+    from neural_spectral_codec_amd.encoding import SpectralEncoder
+    enc = SpectralEncoder(n_elevation=16)
+    with pytest.raises(_lib.NscError):
+        enc.encode_points(np.zeros((4, 4), np.float32))
+    with pytest.raises(_lib.NscError):
+        enc.forward(torch.zeros(1, 16, 360))
+
+
+@pytest.mark.parametrize("bias", [0, 1, -1])
+def test_binning_margins_host(tmp_path, bias):
+    """Fast estimate vs exact chain on 3e6 points (incl. points parked on bin edges), with the
+    1-ULP error of v_rcp_f32 / v_sqrt_f32 pushed to either side."""
+    exe = str(tmp_path / f"bc{bias}")
+    cmd = ["g++", "-O2", "-ffp-contract=off", f"-I{CSRC}", os.path.join(ROOT, "tests", "native", "binning_check.cpp"),
+           "-o", exe, "-lm"]
+    if bias:
+        cmd.insert(3, f"-DNSC_TEST_APPROX_BIAS={bias}")
+    subprocess.check_call(cmd)
+    for args in (["3000000", "7"], ["1000000", "8", "-15", "15", "16", "0"], ["1000000", "9", "-45", "45", "64", "1"]):
+        out = subprocess.check_output([exe] + args).decode().split()
+        n, azu, elu, azw, elw = map(int, out[:5])
+        assert azw == 0 and elw == 0, out
+        assert float(out[5]) < 1e-4          # column-edge slack of the exact float32 chain

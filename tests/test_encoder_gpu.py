@@ -1,0 +1,180 @@
+"""Parity of the HIP encoder (through the C ABI) against the CPU oracle and the reference goldens.
+
+Bars (north_star): range image bit-exact; histogram bin indices bit-exact (LUT);
+descriptor |gpu - oracle| <= 1e-6*|oracle| + 1e-9 (both evaluate the DFT in float64), and
+|gpu - reference| <= 1e-5*|ref| + 1e-7 (the reference runs a float32 FFT).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nsc_oracle as orc
+from neural_spectral_codec_amd import synth
+from neural_spectral_codec_amd.encoding import SpectralEncoder
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "enc_*.npz")))
+CLEAN = {"uniform20k", "safe20k", "uniform120k", "adversarial", "wide20k", "xyz_only", "empty",
+         "single_pt", "e64_ring"}
+
+
+def _enc(E=16, elevation_range=(-24.8, 2.0), **kw):
+    return SpectralEncoder(n_elevation=E, n_azimuth=360, n_bins=50, alpha=2.0,
+                           target_elevation_bins=16, elevation_range=elevation_range, **kw).to("cuda")
+
+
+def _close(d, ref, rtol, atol):
+    return np.all(np.abs(d - ref) <= rtol * np.abs(ref) + atol)
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c)[4:-4] for c in CASES])
+def test_golden_clouds(path):
+    g = np.load(path)
+    name = os.path.basename(path)[4:-4]
+    E, er = int(g["n_elevation"]), tuple(g["elevation_range"])
+    enc = _enc(E, er)
+    d, raw, itp = enc.encode_points_batch([g["points"]], return_images=True)
+    d, raw, itp = d[0].cpu().numpy(), raw[0].cpu().numpy(), itp[0].cpu().numpy()
+    p = orc.default_params(n_elevation=E, elevation_range=er)
+    od, oraw, oitp = orc.encode_points(g["points"], p, want_images=True)
+    assert np.array_equal(raw.view(np.uint32), oraw.view(np.uint32)), "raw range image differs from oracle"
+    assert np.array_equal(itp.view(np.uint32), oitp.view(np.uint32)), "interpolated image differs from oracle"
+    assert _close(d, od, 1e-6, 1e-9)
+    if name in CLEAN:                       # no atan2-ULP edge points: identical to the reference too
+        assert np.array_equal(raw.view(np.uint32), g["ref_raw"])
+        assert np.array_equal(itp.view(np.uint32), g["ref_interp"])
+        assert _close(d, g["ref_desc"], 1e-5, 1e-7)
+
+
+def test_encode_points_api_matches_reference_call_shape():
+    g = np.load(CASES[0])
+    enc = _enc()
+    out = enc.encode_points(g["points"])
+    assert out.shape == (800,) and out.is_cuda
+    host = out.detach().cpu().numpy()       # what pipeline.py:245 does with it
+    assert abs(host.sum() - 1.0) < 1e-5
+
+
+def test_point_bins_match_oracle_and_slow_path_rate():
+    from neural_spectral_codec_amd import _lib
+    rng = np.random.default_rng(0)
+    pts = synth.make_cloud(100, 2_000_000, "uniform")
+    # a block of points sitting on / next to column and row edges
+    n_e = 200_000
+    c = rng.integers(0, 360, n_e)
+    r = rng.integers(0, 17, n_e)
+    az = -np.pi + c * (2 * np.pi / 360) + (rng.uniform(-1, 1, n_e) * 2e-6)
+    lo, hi = np.deg2rad(-24.8), np.deg2rad(2.0)
+    el = lo + r * (hi - lo) / 16 + rng.uniform(-1, 1, n_e) * 2e-6
+    rr = rng.uniform(1, 70, n_e)
+    edge = np.stack([rr * np.cos(el) * np.cos(az), rr * np.cos(el) * np.sin(az), rr * np.sin(el),
+                     np.zeros(n_e)], 1).astype(np.float32)
+    axis = np.zeros((8, 4), np.float32)
+    axis[:, :3] = [[5, 0, 0], [-5, 0, 0], [0, 5, 0], [0, -5, 0], [-5, -0.0, 0], [3, 3, 0], [-3, 3, 1], [0, 0, 5]]
+    allp = np.concatenate([pts, edge, axis], 0)
+    p = orc.default_params()
+    _, oidx, _ = orc.project(allp, p, want_idx=True)
+    enc = _enc()
+    t = torch.from_numpy(allp).cuda()
+    idx = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+    fl = torch.empty(len(allp), dtype=torch.uint8, device="cuda")
+    st = _lib.lib().nsc_debug_point_bins(_lib.ptr(t), len(allp), 4, enc._params(), _lib.ptr(idx),
+                                         _lib.ptr(fl), _lib.stream_ptr(t.device))
+    assert st == 0
+    torch.cuda.synchronize()
+    idx, fl = idx.cpu().numpy(), fl.cpu().numpy()
+    assert np.array_equal(idx, oidx)
+    kept = oidx[:len(pts)] >= 0
+    slow = (fl[:len(pts)][kept] != 0).mean()
+    print(f"exact-path fraction on uniform cloud: {slow:.2e}")
+    assert slow < 2e-3                       # the float64 atan2 path must stay rare
+
+
+def test_ragged_batch_and_empty_clouds():
+    enc = _enc()
+    sizes = [5000, 0, 1, 17000, 333, 0, 2048]
+    clouds = [synth.make_cloud(200 + i, n, "uniform") if n else np.zeros((0, 4), np.float32)
+              for i, n in enumerate(sizes)]
+    d = enc.encode_points_batch(clouds).cpu().numpy()
+    for i, c in enumerate(clouds):
+        od = orc.encode_points(c)
+        assert _close(d[i], od, 1e-6, 1e-9), i
+    assert np.array_equal(d[1], np.full(800, np.float32(1) / np.float32(800)))
+
+
+def test_split_path_small_batch_of_big_clouds():
+    """3 x 120k points: clouds are split over workgroups and merged with global atomicMin."""
+    enc = _enc()
+    clouds = [synth.make_cloud(300 + i, 120000, k) for i, k in enumerate(["uniform", "ring", "wide"])]
+    d, raw, itp = enc.encode_points_batch(clouds, return_images=True)
+    for i, c in enumerate(clouds):
+        od, oraw, oitp = orc.encode_points(c, want_images=True)
+        assert np.array_equal(raw[i].cpu().numpy().view(np.uint32), oraw.view(np.uint32))
+        assert np.array_equal(itp[i].cpu().numpy().view(np.uint32), oitp.view(np.uint32))
+        assert _close(d[i].cpu().numpy(), od, 1e-6, 1e-9)
+
+
+def test_fused_path_large_batch_and_point_order_invariance():
+    """600 clouds x 3000 points -> one workgroup per cloud.  min() is order-free: shuffling the
+    points of a cloud must give bit-identical output."""
+    enc = _enc()
+    pts, off = synth.make_clouds_packed(range(400, 1000), 3000, "uniform")
+    d = enc.encode_points_batch((torch.from_numpy(pts), torch.from_numpy(off))).cpu().numpy()
+    od = orc.encode_clouds(pts, off, n_threads=8)
+    assert _close(d, od, 1e-6, 1e-9)
+    rng = np.random.default_rng(1)
+    sh = pts.copy()
+    for c in range(len(off) - 1):
+        sh[off[c]:off[c + 1]] = pts[off[c]:off[c + 1]][rng.permutation(off[c + 1] - off[c])]
+    d2 = enc.encode_points_batch((torch.from_numpy(sh), torch.from_numpy(off))).cpu().numpy()
+    assert np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+
+
+def test_forward_on_range_images(golden_dir):
+    g = np.load(os.path.join(golden_dir, "range_images.npz"))
+    enc = _enc()
+    p = orc.default_params()
+    for key_i, key_d in (("imgs16", "desc16"), ("imgs64", "desc64")):
+        d = enc.forward(torch.from_numpy(g[key_i]).cuda()).cpu().numpy()
+        for i in range(len(d)):
+            assert _close(d[i], orc.encode_range_image(g[key_i][i], p), 1e-6, 1e-9)
+            assert _close(d[i], g[key_d][i], 1e-5, 1e-7)
+    one = enc.encode_range_image(torch.from_numpy(g["imgs16"][0]).cuda()).cpu().numpy()
+    assert _close(one, g["desc16"][0], 1e-5, 1e-7)
+
+
+def test_float32_row_math_mode():
+    """numpy 1.24 value-based casting: row index computed in float32 (elev_f64 = 0)."""
+    enc = _enc(elev_float64=False)
+    c = synth.make_cloud(77, 50000, "uniform")
+    d, raw, _ = enc.encode_points_batch([c], return_images=True)
+    p = orc.default_params(elev_f64=0)
+    od, oraw, _ = orc.encode_points(c, p, want_images=True)
+    assert np.array_equal(raw[0].cpu().numpy().view(np.uint32), oraw.view(np.uint32))
+    assert _close(d[0].cpu().numpy(), od, 1e-6, 1e-9)
+
+
+def test_other_alpha_and_bins():
+    enc = SpectralEncoder(n_elevation=16, n_bins=32, alpha=1.0, target_elevation_bins=16).to("cuda")
+    c = synth.make_cloud(78, 30000, "ring")
+    d = enc.encode_points(c).cpu().numpy()
+    p = orc.default_params(n_bins=32)
+    lut = orc.bin_lut(1.0, 32, 181, 1e-8)[1]
+    assert d.shape == (16 * 32,)
+    assert _close(d, orc.encode_points(c, p, lut), 1e-6, 1e-9)
+
+
+def test_bench_sized_batch_sampled_against_oracle():
+    """Full-size clouds generated in HBM (bench workload shape, 64 clouds here); sample checked."""
+    enc = _enc()
+    pts, off = synth.make_clouds_device(64, 120000, "cuda", seed=3)
+    d = enc.encode_points_batch((pts, off))
+    torch.cuda.synchronize()
+    assert torch.allclose(d.sum(1), torch.ones(64, device="cuda"), atol=1e-5)
+    for c in (0, 31, 63):
+        host = pts[c * 120000:(c + 1) * 120000].cpu().numpy()
+        assert _close(d[c].cpu().numpy(), orc.encode_points(host), 1e-6, 1e-9)

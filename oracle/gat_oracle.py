@@ -1,0 +1,161 @@
+"""CPU restatement (pure torch, float32) of the reference GNN forward for the GAT hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by the product package.
+
+Parity status: PARITY UNPINNED BY THE REFERENCE.  The arithmetic of this stage lives in the
+third-party dependency torch-geometric==2.4.0 (reference requirements.txt:3, setup.py:26; call
+sites src/gnn/model.py:16,75-84,127,129,180), which is absent from /root/reference and from this
+image, and the reference holds no tests or golden vectors at that boundary.  This file restates
+the published GATConv(heads=1, concat=False, add_self_loops=True, fill_value='mean',
+negative_slope=0.2, bias=True) algorithm and src/gnn/model.py:96-153 around
+it; it is pinned by an independent dense-adjacency formulation (gatconv_dense) and by invariants
+(tests/test_gat_oracle.py), not by reference outputs.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def add_self_loops_mean(edge_index, edge_attr, n):
+    """PyG remove_self_loops + add_self_loops(fill_value='mean'): self loops are dropped, N loops
+    (i,i) are appended LAST, their attribute = mean of the attributes of edges entering i."""
+    keep = edge_index[0] != edge_index[1]
+    ei = edge_index[:, keep]
+    loops = torch.arange(n, dtype=edge_index.dtype, device=edge_index.device)
+    ea = None
+    if edge_attr is not None:
+        ea = edge_attr[keep]
+        d = ea.shape[1]
+        s = torch.zeros((n, d), dtype=ea.dtype, device=ea.device).index_add_(0, ei[1], ea)
+        cnt = torch.zeros(n, dtype=ea.dtype, device=ea.device).index_add_(
+            0, ei[1], torch.ones(ei.shape[1], dtype=ea.dtype, device=ea.device))
+        loop_ea = s / cnt.clamp(min=1).unsqueeze(1)
+        ea = torch.cat([ea, loop_ea], 0)
+    ei = torch.cat([ei, torch.stack([loops, loops])], 1)
+    return ei, ea
+
+
+def gatconv_reference(x, edge_index, edge_attr, lin_w, att_src, att_dst, lin_edge_w, att_edge, bias,
+                      negative_slope=0.2, return_alpha=False):
+    """GATConv 2.4.0 forward, heads=1.  edge_index[0]=source j, [1]=target i."""
+    n = x.shape[0]
+    h = x @ lin_w.t()
+    a_src = (h * att_src.view(1, -1)).sum(-1)
+    a_dst = (h * att_dst.view(1, -1)).sum(-1)
+    ei, ea = add_self_loops_mean(edge_index, edge_attr if lin_edge_w is not None else None, n)
+    j, i = ei[0], ei[1]
+    logit = a_src[j] + a_dst[i]
+    if ea is not None and lin_edge_w is not None:
+        logit = logit + ((ea @ lin_edge_w.t()) * att_edge.view(1, -1)).sum(-1)
+    logit = F.leaky_relu(logit, negative_slope)
+    m = torch.full((n,), float("-inf"), dtype=x.dtype).scatter_reduce(0, i, logit, "amax", include_self=True)
+    p = torch.exp(logit - m[i])
+    den = torch.zeros(n, dtype=x.dtype).index_add_(0, i, p)
+    alpha = p / (den[i] + 1e-16)
+    out = torch.zeros_like(h).index_add_(0, i, alpha.unsqueeze(1) * h[j])
+    out = out + bias
+    return (out, ei, alpha) if return_alpha else out
+
+
+def gatconv_dense(x, edge_index, edge_attr, lin_w, att_src, att_dst, lin_edge_w, att_edge, bias,
+                  negative_slope=0.2):
+    """Independent formulation: dense (N,N) masked softmax.  Requires a simple graph (no duplicate
+    edges); used only to cross-check gatconv_reference on small graphs."""
+    n = x.shape[0]
+    h = (x.double() @ lin_w.double().t())
+    s = h @ att_src.double().view(-1)
+    d = h @ att_dst.double().view(-1)
+    logits = torch.full((n, n), float("-inf"), dtype=torch.float64)        # [target i, source j]
+    has_edge = torch.zeros((n, n), dtype=torch.bool)
+    ea_dense = None
+    if edge_attr is not None and lin_edge_w is not None:
+        ea_dense = torch.zeros((n, n, edge_attr.shape[1]), dtype=torch.float64)
+    for e in range(edge_index.shape[1]):
+        j, i = int(edge_index[0, e]), int(edge_index[1, e])
+        if i == j:
+            continue
+        assert not has_edge[i, j], "dense cross-check needs a simple graph"
+        has_edge[i, j] = True
+        if ea_dense is not None:
+            ea_dense[i, j] = edge_attr[e].double()
+    if ea_dense is not None:
+        cnt = has_edge.sum(1).clamp(min=1).double()
+        loop = (ea_dense * has_edge.unsqueeze(-1)).sum(1) / cnt.unsqueeze(1)
+        for i in range(n):
+            ea_dense[i, i] = loop[i]
+    for i in range(n):
+        has_edge[i, i] = True
+    v = None
+    if ea_dense is not None:
+        v = lin_edge_w.double().t() @ att_edge.double().view(-1)         # (edge_dim,)
+    raw = s.view(1, n) + d.view(n, 1)
+    if v is not None:
+        raw = raw + ea_dense @ v
+    raw = F.leaky_relu(raw, negative_slope)
+    logits = torch.where(has_edge, raw, logits)
+    alpha = torch.softmax(logits, dim=1)
+    return (alpha @ h + bias.double()).float()
+
+
+def _bn(x, bn, training):
+    if training:
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    return (x - mean) / torch.sqrt(var + bn.eps) * bn.weight + bn.bias
+
+
+def forward_reference(model, data, training=False):
+    """src/gnn/model.py:96-153 with the module's own parameters, on the CPU in float32.
+    training=True uses batch statistics in BatchNorm and NO dropout (dropout is stochastic and
+    unseeded in the reference; parity runs use dropout=0)."""
+    gnn = getattr(model, "gnn", model)                                  # LocalUpdateGNN wrapper :230
+    sd = {k: v.detach().cpu().float() for k, v in gnn.state_dict().items()}
+    x = data.x.detach().cpu().float()
+    ei = data.edge_index.detach().cpu()
+    ea = getattr(data, "edge_attr", None)
+    ea = ea.detach().cpu().float() if ea is not None else None
+    use_edge = ea is not None and gnn.edge_dim is not None               # :126
+
+    class _B:                                                            # tiny BN view over the state dict
+        def __init__(self, prefix):
+            self.weight, self.bias = sd[prefix + ".weight"], sd[prefix + ".bias"]
+            self.running_mean, self.running_var = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+            self.eps = 1e-5
+
+    x_input = x
+    h = x @ sd["input_proj.weight"].t() + sd["input_proj.bias"]          # :116
+    h = F.relu(_bn(h, _B("input_norm"), training))                       # :117-118
+    n_layers = gnn.n_layers
+    for l in range(n_layers):
+        h_prev = h
+        pre = f"convs.{l}."
+        h = gatconv_reference(
+            h, ei, ea if use_edge else None, sd[pre + "lin_src.weight"], sd[pre + "att_src"],
+            sd[pre + "att_dst"], sd.get(pre + "lin_edge.weight") if use_edge else None,
+            sd.get(pre + "att_edge") if use_edge else None, sd[pre + "bias"])          # :126-129
+        h = _bn(h, _B(f"batch_norms.{l}"), training)                     # :132
+        if l < n_layers - 1:
+            h = F.relu(h)                                                # :135-137 (dropout off)
+        if gnn.residual and 0 < l < n_layers - 1:
+            h = h + h_prev                                               # :140-141
+    out = h @ sd["output_proj.weight"].t() + sd["output_proj.bias"]      # :144
+    if gnn.residual:
+        if "residual_proj.weight" in sd:
+            out = out + x_input @ sd["residual_proj.weight"].t() + sd["residual_proj.bias"]
+        else:
+            out = out + x_input                                          # :147-151
+    return out
+
+
+def randomize_bn_stats(model, seed=1):
+    """Give every BatchNorm non-trivial running stats and affine terms (fresh modules have 0/1)."""
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                m.running_mean.copy_((torch.randn(m.num_features, generator=g) * 0.1).to(m.running_mean.device))
+                m.running_var.copy_((torch.rand(m.num_features, generator=g) * 1.5 + 0.25).to(m.running_var.device))
+                m.weight.copy_((torch.rand(m.num_features, generator=g) + 0.5).to(m.weight.device))
+                m.bias.copy_((torch.randn(m.num_features, generator=g) * 0.1).to(m.bias.device))

@@ -95,6 +95,72 @@ int nsc_debug_point_bins(const float *pts, int64_t n_points, int32_t stride_floa
                          const NscEncParams *p, int32_t *out_idx, uint8_t *out_flags /*nullable*/,
                          void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * GNN enhancer: Linear 800->256 + BN + ReLU, 3 x GATConv(256->256, heads=1, edge_dim) + BN,
+ * Linear 256->800 + input residual.  Replaces SpectralGNN.forward / forward_with_attention
+ * (reference src/gnn/model.py:96-153, :155-201) and the torch_geometric 2.4.0 GATConv it calls
+ * (model.py:16,75-84,127; algorithm restated in SURVEY.md Appendix B).
+ * ------------------------------------------------------------------------------------------ */
+#define NSC_GAT_MAX_LAYERS 8
+#define NSC_GAT_MAX_EDGE_DIM 8
+
+typedef struct NscGatLayer {      /* device pointers; names are the reference's state-dict keys */
+    const float *lin_w;           /* convs.{l}.lin_src.weight (H,H)  (lin_dst is the same tensor)   */
+    const float *att_src;         /* convs.{l}.att_src (H)                                          */
+    const float *att_dst;         /* convs.{l}.att_dst (H)                                          */
+    const float *lin_edge_w;      /* convs.{l}.lin_edge.weight (H,edge_dim), NULL without edge_dim  */
+    const float *att_edge;        /* convs.{l}.att_edge (H), NULL without edge_dim                  */
+    const float *bias;            /* convs.{l}.bias (H)                                             */
+    const float *bn_w, *bn_b, *bn_mean, *bn_var;   /* batch_norms.{l}.{weight,bias,running_*} (H)  */
+} NscGatLayer;
+
+typedef struct NscGatModel {
+    int32_t in_dim;               /* 800   model.py:33 */
+    int32_t hidden;               /* 256   model.py:34 (multiple of 4, <= 1024) */
+    int32_t out_dim;              /* 800   model.py:35 */
+    int32_t n_layers;             /* 3     model.py:36 */
+    int32_t edge_dim;             /* 0 = GATConv built without edge_dim (pipeline.py:158-166) */
+    int32_t residual;             /* model.py:39 */
+    float   bn_eps;               /* 1e-5 */
+    float   negative_slope;       /* 0.2 (GATConv default) */
+    const float *in_w, *in_b;     /* input_proj.{weight (H,in), bias (H)}      model.py:67 */
+    const float *in_bn_w, *in_bn_b, *in_bn_mean, *in_bn_var;   /* input_norm.* model.py:68 */
+    const float *out_w, *out_b;   /* output_proj.{weight (out,H), bias (out)}  model.py:88 */
+    const float *res_w, *res_b;   /* residual_proj.* (out,in) or NULL when in_dim == out_dim (model.py:91-94) */
+    NscGatLayer layers[NSC_GAT_MAX_LAYERS];
+} NscGatModel;
+
+/* Graph in CSR-by-target form with PyG's self-loop convention applied (existing self loops removed,
+ * one loop per node appended last, its edge attribute = mean of the node's incoming edge attributes). */
+typedef struct NscGraph {
+    int32_t n_nodes;
+    int32_t nnz;                  /* kept edges + n_nodes self loops */
+    const int32_t *row_ptr;       /* (n_nodes+1) */
+    const int32_t *src;           /* (nnz) source node of each entry, entries of a target in edge order */
+    const int32_t *eid;           /* (nnz) index into the caller's edge list, -1 for the self loop */
+    const float   *loop_attr;     /* (n_nodes, edge_dim) or NULL */
+} NscGraph;
+
+size_t nsc_graph_workspace_bytes(int32_t n_nodes, int64_t n_edges);
+
+/* edge_index (2,E) int64 [row 0 = source j, row 1 = target i] -> CSR arrays (caller-allocated:
+ * row_ptr n_nodes+1, src/eid E+n_nodes, loop_attr n_nodes*edge_dim).  nnz_out (device int32) receives
+ * row_ptr[n_nodes].  Edges with an endpoint outside [0,n_nodes) are dropped. */
+int nsc_graph_build_csr(const int64_t *edge_index, int64_t n_edges, int32_t n_nodes,
+                        const float *edge_attr, int32_t edge_dim, int32_t *row_ptr, int32_t *src,
+                        int32_t *eid, float *loop_attr, void *ws, size_t ws_bytes, void *stream);
+
+size_t nsc_gat_workspace_bytes(const NscGatModel *m, int32_t n_nodes);
+
+/* Inference forward (BatchNorm running statistics, no dropout) == model.eval(); model(data).
+ *   x          (n_nodes, in_dim) float32
+ *   edge_attr  (E, edge_dim) float32 indexed by g->eid, or NULL (then the edge term is skipped,
+ *              as model.py:126-129 does when data has no edge_attr)
+ *   out        (n_nodes, out_dim) float32
+ *   alpha_out  nullable (n_layers, nnz) attention coefficients (forward_with_attention) */
+int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
+                    float *out, float *alpha_out, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

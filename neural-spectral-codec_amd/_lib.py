@@ -23,6 +23,36 @@ class EncParams(C.Structure):
     ]
 
 
+class GatLayer(C.Structure):
+    """struct NscGatLayer"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "lin_w", "att_src", "att_dst", "lin_edge_w", "att_edge", "bias",
+        "bn_w", "bn_b", "bn_mean", "bn_var")]
+
+
+GAT_MAX_LAYERS = 8
+GAT_MAX_EDGE_DIM = 8
+
+
+class GatModel(C.Structure):
+    """struct NscGatModel"""
+    _fields_ = [
+        ("in_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32), ("n_layers", C.c_int32),
+        ("edge_dim", C.c_int32), ("residual", C.c_int32), ("bn_eps", C.c_float),
+        ("negative_slope", C.c_float),
+        ("in_w", C.c_void_p), ("in_b", C.c_void_p),
+        ("in_bn_w", C.c_void_p), ("in_bn_b", C.c_void_p), ("in_bn_mean", C.c_void_p), ("in_bn_var", C.c_void_p),
+        ("out_w", C.c_void_p), ("out_b", C.c_void_p), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
+        ("layers", GatLayer * GAT_MAX_LAYERS),
+    ]
+
+
+class Graph(C.Structure):
+    """struct NscGraph"""
+    _fields_ = [("n_nodes", C.c_int32), ("nnz", C.c_int32), ("row_ptr", C.c_void_p),
+                ("src", C.c_void_p), ("eid", C.c_void_p), ("loop_attr", C.c_void_p)]
+
+
 _lib = None
 
 # every symbol include/nsc.h declares: (restype, argtypes)
@@ -36,6 +66,10 @@ SYMBOLS = {
     "nsc_encode_clouds": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nsc_encode_range_images": (C.c_int, [_vp, _i32, _i32, _pp, _vp, _vp, _vp]),
     "nsc_debug_point_bins": (C.c_int, [_vp, _i64, _i32, _pp, _vp, _vp, _vp]),
+    "nsc_graph_workspace_bytes": (_sz, [_i32, _i64]),
+    "nsc_graph_build_csr": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_gat_workspace_bytes": (_sz, [C.POINTER(GatModel), _i32]),
+    "nsc_gat_forward": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

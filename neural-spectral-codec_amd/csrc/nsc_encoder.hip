@@ -19,6 +19,7 @@
 // Built with -ffp-contract=off: float32/float64 expressions round exactly as written; FMAs appear
 // only where fma()/__builtin_fmaf is spelled out.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/nsc.h"
 #include "nsc_math.h"
@@ -33,13 +34,13 @@ constexpr int F = NSC_F;      // 181 rfft bins
 constexpr int NH = 180;       // complex length of the packed real FFT
 constexpr int MAXR = 16;      // target rows the finish stage supports
 constexpr int MAXE = 64;      // projector rows the LDS image supports
-constexpr int MAGS_STRIDE = 184;
 
 struct EncDev {
     NscBinParams bp;
     int E, R, B;
     float eps;
     int interp;
+    int dev_skip_finish;   // development knob (NSC_TUNE_SKIP_FINISH): time the scatter phase alone
 };
 
 // exp(-2 pi i j / 360) = (cos, -sin): table holds (cos, sin)
@@ -51,20 +52,22 @@ __device__ const double2 g_tw360[A] = {
 // LDS carve-up (bytes), identical on host and device
 // ---------------------------------------------------------------------------------------------
 struct LdsPlan {
-    int img, pool, tw, fft, mags, hist, seg, misc, total;
+    int img, pool, tw, fft, seg, misc, total;
 };
+
+constexpr int TW_N = 240;        // twiddle indices used: stages <= 2*2*59 = 236, unpack <= 180
+constexpr int ROW_BYTES = A * 4; // one image row; once a row's FFT has read it, the row's bytes are
+constexpr int HIST_OFF = 736;    // reused: |X| magnitudes at +0 (181 floats), histogram at +736
+constexpr int MAXB = (ROW_BYTES - HIST_OFF) / 4;   // 176 bins fit behind the magnitudes
 
 __host__ __device__ inline LdsPlan lds_plan(int E, int R, int B, int nw)
 {
     LdsPlan p;
     int o = 0;
-    p.img = o;  o += E * A * 4;
-    p.pool = o; o += (E != R) ? R * A * 4 : 0;
-    o = (o + 15) & ~15;
-    p.tw = o;   o += A * 16;
+    p.img = o;  o += E * ROW_BYTES;
+    p.pool = o; o += (E != R) ? R * ROW_BYTES : 0;
+    p.tw = o;   o += TW_N * 16;
     p.fft = o;  o += nw * NH * 16;
-    p.mags = o; o += nw * MAGS_STRIDE * 4;
-    p.hist = o; o += ((R * B * 4) + 15) & ~15;
     p.seg = o;  o += ((2 * B * 4) + 15) & ~15;
     p.misc = o; o += MAXR * 8 + MAXE * 4 + MAXE * 4;   // rowsum f64[16], rowflag int[64], rowsrc int[64]
     p.total = o;
@@ -205,70 +208,147 @@ __device__ __forceinline__ int interp_row(float *row, int lane, bool do_interp)
 
 // ---------------------------------------------------------------------------------------------
 // 360-point real FFT magnitude of one row (one wavefront), float64
-//   z[n] = x[2n] + i x[2n+1], n < 180;  180 = 12 x 15 Cooley-Tukey (n = 15 n1 + n2, k = k1 + 12 k2);
-//   X[k] = E[k] + W360^k O[k] unpacking for k = 0..180.          spectral_encoder.py:180-186
+//   z[n] = x[2n] + i x[2n+1], n < 180;  180 = 4 x 5 x 3 x 3 mixed-radix Stockham autosort: stage with
+//   radix R and Ns = product of the earlier radices, butterfly j < 180/R, k = j mod Ns:
+//       v[r] = in[j + r*180/R] * W^(r k), W = exp(-2 pi i/(Ns R));  v = DFT_R(v);
+//       out[(j div Ns) Ns R + k + q Ns] = v[q]
+//   The small DFTs are register butterflies with literal constants; the only LDS twiddle reads are
+//   the R-1 inter-stage factors, issued together.  One wave owns the row and LDS executes a wave's
+//   operations in order, so every stage works in place (all reads precede all writes in program
+//   order).  X[k] = E[k] + W360^k O[k] unpacking for k = 0..180.     spectral_encoder.py:180-186
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void twmul(double &re, double &im, const double2 w)   // *= (w.x - i w.y)
+{
+    const double r = fma(re, w.x, im * w.y);
+    const double i = fma(im, w.x, -(re * w.y));
+    re = r; im = i;
+}
+
+__device__ __forceinline__ void dft3(double (&re)[3], double (&im)[3])
+{
+    constexpr double S = 0.86602540378443864676;       // sin(2 pi / 3)
+    const double t1r = re[1] + re[2], t1i = im[1] + im[2];
+    const double t2r = fma(-0.5, t1r, re[0]), t2i = fma(-0.5, t1i, im[0]);
+    const double t3r = S * (re[1] - re[2]), t3i = S * (im[1] - im[2]);
+    re[0] = re[0] + t1r; im[0] = im[0] + t1i;
+    re[1] = t2r + t3i;   im[1] = t2i - t3r;            // t2 - i t3
+    re[2] = t2r - t3i;   im[2] = t2i + t3r;            // t2 + i t3
+}
+
+__device__ __forceinline__ void dft4(double (&re)[4], double (&im)[4])
+{
+    const double t0r = re[0] + re[2], t0i = im[0] + im[2];
+    const double t1r = re[0] - re[2], t1i = im[0] - im[2];
+    const double t2r = re[1] + re[3], t2i = im[1] + im[3];
+    const double t3r = re[1] - re[3], t3i = im[1] - im[3];
+    re[0] = t0r + t2r; im[0] = t0i + t2i;
+    re[2] = t0r - t2r; im[2] = t0i - t2i;
+    re[1] = t1r + t3i; im[1] = t1i - t3r;              // t1 - i t3
+    re[3] = t1r - t3i; im[3] = t1i + t3r;              // t1 + i t3
+}
+
+__device__ __forceinline__ void dft5(double (&re)[5], double (&im)[5])
+{
+    constexpr double C1 = 0.30901699437494742410;      // cos(2 pi / 5)
+    constexpr double C2 = -0.80901699437494742410;     // cos(4 pi / 5)
+    constexpr double S1 = 0.95105651629515357212;      // sin(2 pi / 5)
+    constexpr double S2 = 0.58778525229247312917;      // sin(4 pi / 5)
+    const double t1r = re[1] + re[4], t1i = im[1] + im[4];
+    const double t2r = re[2] + re[3], t2i = im[2] + im[3];
+    const double t3r = re[1] - re[4], t3i = im[1] - im[4];
+    const double t4r = re[2] - re[3], t4i = im[2] - im[3];
+    const double m1r = fma(C2, t2r, fma(C1, t1r, re[0])), m1i = fma(C2, t2i, fma(C1, t1i, im[0]));
+    const double m2r = fma(C1, t2r, fma(C2, t1r, re[0])), m2i = fma(C1, t2i, fma(C2, t1i, im[0]));
+    const double n1r = fma(S2, t4r, S1 * t3r), n1i = fma(S2, t4i, S1 * t3i);
+    const double n2r = fma(-S1, t4r, S2 * t3r), n2i = fma(-S1, t4i, S2 * t3i);
+    re[0] = re[0] + t1r + t2r; im[0] = im[0] + t1i + t2i;
+    re[1] = m1r + n1i; im[1] = m1i - n1r;              // m1 - i n1
+    re[4] = m1r - n1i; im[4] = m1i + n1r;              // m1 + i n1
+    re[2] = m2r + n2i; im[2] = m2i - n2r;              // m2 - i n2
+    re[3] = m2r - n2i; im[3] = m2i + n2r;              // m2 + i n2
+}
+
 __device__ __forceinline__ void fft_row(const float *x, double2 *buf, const double2 *tw, float *mags,
                                         int lane)
 {
-    if (lane < 60) {                                   // stage 1: 15 DFTs of length 12 over n1
-        const int n2 = lane % 15, g = lane / 15;
-        double zr[12], zi[12];
+    {   // stage 1: R = 4, Ns = 1, 45 butterflies, input straight from the float32 image row
+        double re[4], im[4];
+        if (lane < 45) {
 #pragma unroll
-        for (int n1 = 0; n1 < 12; ++n1) {
-            const f32x2 v = *reinterpret_cast<const f32x2 *>(&x[2 * (15 * n1 + n2)]);
-            zr[n1] = (double)v.x;
-            zi[n1] = (double)v.y;
-        }
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const int k1 = 3 * g + o;
-            const int step = 30 * k1;                  // W12^(n1 k1) = W360^(30 n1 k1)
-            double re = 0.0, im = 0.0;
-            int j = 0;
-#pragma unroll
-            for (int n1 = 0; n1 < 12; ++n1) {
-                const double2 w = tw[j];
-                re = fma(zr[n1], w.x, re); re = fma(zi[n1], w.y, re);
-                im = fma(zi[n1], w.x, im); im = fma(-zr[n1], w.y, im);
-                j += step; j -= (j >= A) ? A : 0;
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(&x[2 * (lane + 45 * r)]);
+                re[r] = (double)v.x; im[r] = (double)v.y;
             }
-            const double2 w = tw[2 * n2 * k1];         // W180^(n2 k1), 2*14*11 < 360
-            double2 y;
-            y.x = fma(re, w.x, im * w.y);
-            y.y = fma(im, w.x, -(re * w.y));
-            buf[k1 * 15 + n2] = y;
+            dft4(re, im);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[4 * lane + q] = o; }
         }
     }
     wave_sync();
-    double yr[15], yi[15];
-    if (lane < 60) {                                   // stage 2: 12 DFTs of length 15 over n2
-        const int k1 = lane % 12;
+    {   // stage 2: R = 5, Ns = 4, 36 butterflies, W = W360^(18 r k)
+        double re[5], im[5];
+        const int k = lane & 3;
+        if (lane < 36) {
+            double2 w[5];
 #pragma unroll
-        for (int n2 = 0; n2 < 15; ++n2) {
-            const double2 v = buf[k1 * 15 + n2];
-            yr[n2] = v.x;
-            yi[n2] = v.y;
+            for (int r = 0; r < 5; ++r) {
+                const double2 v = buf[lane + 36 * r];
+                re[r] = v.x; im[r] = v.y;
+                if (r) w[r] = tw[18 * r * k];
+            }
+#pragma unroll
+            for (int r = 1; r < 5; ++r) twmul(re[r], im[r], w[r]);
+            dft5(re, im);
+        }
+        wave_sync();
+        if (lane < 36) {
+            const int j0 = (lane >> 2) * 20 + k;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[j0 + 4 * q] = o; }
         }
     }
-    wave_sync();                                       // every lane has its inputs: safe to overwrite buf
-    if (lane < 60) {
-        const int k1 = lane % 12, g = lane / 12;
+    wave_sync();
+    {   // stage 3: R = 3, Ns = 20, 60 butterflies, W = W360^(6 r k)
+        double re[3], im[3];
+        const int k = lane % 20;
+        if (lane < 60) {
+            double2 w[3];
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const int k2 = 3 * g + o;
-            const int step = 24 * k2;                  // W15^(n2 k2) = W360^(24 n2 k2)
-            double re = 0.0, im = 0.0;
-            int j = 0;
-#pragma unroll
-            for (int n2 = 0; n2 < 15; ++n2) {
-                const double2 w = tw[j];
-                re = fma(yr[n2], w.x, re); re = fma(yi[n2], w.y, re);
-                im = fma(yi[n2], w.x, im); im = fma(-yr[n2], w.y, im);
-                j += step; j -= (j >= A) ? A : 0;
+            for (int r = 0; r < 3; ++r) {
+                const double2 v = buf[lane + 60 * r];
+                re[r] = v.x; im[r] = v.y;
+                if (r) w[r] = tw[6 * r * k];
             }
-            double2 z; z.x = re; z.y = im;
-            buf[k1 + 12 * k2] = z;
+            twmul(re[1], im[1], w[1]);
+            twmul(re[2], im[2], w[2]);
+            dft3(re, im);
+        }
+        wave_sync();
+        if (lane < 60) {
+            const int j0 = (lane / 20) * 60 + k;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[j0 + 20 * q] = o; }
+        }
+    }
+    wave_sync();
+    {   // stage 4: R = 3, Ns = 60, 60 butterflies, W = W360^(2 r k), k = j
+        double re[3], im[3];
+        if (lane < 60) {
+            double2 w[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double2 v = buf[lane + 60 * r];
+                re[r] = v.x; im[r] = v.y;
+                if (r) w[r] = tw[2 * r * lane];
+            }
+            twmul(re[1], im[1], w[1]);
+            twmul(re[2], im[2], w[2]);
+            dft3(re, im);
+        }
+        wave_sync();
+        if (lane < 60) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[lane + 60 * q] = o; }
         }
     }
     wave_sync();
@@ -314,20 +394,25 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
     float *pool = reinterpret_cast<float *>(lds + lp.pool);
     double2 *tw = reinterpret_cast<double2 *>(lds + lp.tw);
     double2 *fftbuf = reinterpret_cast<double2 *>(lds + lp.fft) + wave * NH;
-    float *mags = reinterpret_cast<float *>(lds + lp.mags) + wave * MAGS_STRIDE;
-    float *hist = reinterpret_cast<float *>(lds + lp.hist);
     int *seg = reinterpret_cast<int *>(lds + lp.seg);
     double *rowsum = reinterpret_cast<double *>(lds + lp.misc);
     int *rowflag = reinterpret_cast<int *>(lds + lp.misc + MAXR * 8);
     int *rowsrc = rowflag + MAXE;
 
-    // twiddles and histogram segments (LUT is monotone: bin b owns frequencies [seg[b], seg[B+b]))
-    for (int i = tid; i < A; i += NT) tw[i] = g_tw360[i];
-    for (int b = tid; b < B; b += NT) {
-        int lo = 0, hi = 0;
-        for (int k = 0; k < F; ++k) { const int v = lut[k]; lo += (v < b); hi += (v <= b); }
-        seg[b] = lo;
-        seg[B + b] = hi;
+    // twiddles and histogram segments (LUT is monotone: bin b owns frequencies [seg[b], seg[B+b]);
+    // bins no frequency maps to keep the empty segment [0,0))
+    for (int i = tid; i < TW_N; i += NT) tw[i] = g_tw360[i];
+    for (int b = tid; b < 2 * B; b += NT) seg[b] = 0;
+    int *lut_s = reinterpret_cast<int *>(lds + lp.fft);  // FFT scratch is free until the first FFT
+    if (wave == 0)
+        for (int k = lane; k < F; k += 64) lut_s[k] = lut[k];
+    __syncthreads();
+    if (wave == 0) {
+        for (int k = lane; k < F; k += 64) {
+            const int b = lut_s[k];
+            if (k == 0 || lut_s[k - 1] != b) seg[b] = k;
+            if (k == F - 1 || lut_s[k + 1] != b) seg[B + b] = k + 1;
+        }
     }
 
     if (mode == 0) {
@@ -367,11 +452,9 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
         }
         if (out_interp)
             for (int i = tid; i < E * A; i += NT) out_interp[i] = img[i];
-    } else {
-        __syncthreads();
     }
 
-    const float *rows = img;
+    float *rows = img;
     if (E != R) {                                                 // adaptive_avg_pool2d, :171-176
         for (int i = tid; i < R * A; i += NT) {
             const int pr = i / A, c = i - pr * A;
@@ -382,22 +465,26 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
             pool[i] = s / (float)(r1 - r0);
         }
         rows = pool;
-        __syncthreads();
     }
+    __syncthreads();                                              // also orders lut_s reads before FFT writes
+    if (d.dev_skip_finish & 16) return;
 
     for (int r = wave; r < R; r += NW) {
-        fft_row(rows + r * A, fftbuf, tw, mags, lane);
+        float *row = rows + r * A;
+        float *mags = row;                                        // the row is dead after FFT stage 1
+        float *hist = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(row) + HIST_OFF);
+        if (!(d.dev_skip_finish & 4)) fft_row(row, fftbuf, tw, mags, lane);
         double part = 0.0;
+        if (!(d.dev_skip_finish & 8))
         for (int b = lane; b < B; b += 64) {
             float h = 0.0f;
             const int k1 = seg[B + b];
             for (int k = seg[b]; k < k1; ++k) h += mags[k];      // scatter_add_, ascending k (:152-155)
-            hist[r * B + b] = h;
+            hist[b] = h;
             part += (double)h;
         }
         part = wave_sum(part);
         if (lane == 0) rowsum[r] = part;
-        wave_sync();
     }
     __syncthreads();
 
@@ -407,7 +494,12 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
     const int D = R * B;
     if (s > d.eps) {
         const float den = s + d.eps;                              // :199
-        for (int i = tid; i < D; i += NT) out_desc[i] = hist[i] / den;
+        for (int i = tid; i < D; i += NT) {
+            const int r = i / B, b = i - r * B;
+            const float h = *reinterpret_cast<const float *>(
+                reinterpret_cast<const unsigned char *>(rows + r * A) + HIST_OFF + 4 * b);
+            out_desc[i] = h / den;
+        }
     } else {
         const float u = 1.0f / (float)D;                          // :202
         for (int i = tid; i < D; i += NT) out_desc[i] = u;
@@ -417,8 +509,8 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <int NW, int U>
-__global__ __launch_bounds__(NW * 64) void encode_fused_kernel(
+template <int NW, int U, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void encode_fused_kernel(
     const float *__restrict__ pts, const long long *__restrict__ off, int stride, EncDev d,
     const int *__restrict__ lut, float *__restrict__ out_desc, float *__restrict__ out_raw,
     float *__restrict__ out_interp)
@@ -432,6 +524,10 @@ __global__ __launch_bounds__(NW * 64) void encode_fused_kernel(
     __syncthreads();
     scatter_range<NT, U>(pts, off[c], off[c + 1], stride, tid, d.bp, img);
     __syncthreads();
+    if (d.dev_skip_finish & 1) {
+        if (tid == 0) out_desc[(long long)c * d.R * d.B] = __uint_as_float(img[0]);
+        return;
+    }
     const long long D = (long long)d.R * d.B;
     finish_image<NW>(lds, d, 0, lut, out_desc + c * D,
                      out_raw ? out_raw + (long long)c * npix : nullptr,
@@ -475,13 +571,25 @@ __global__ __launch_bounds__(NW * 64) void finish_kernel(
     constexpr int NT = NW * 64;
     const int c = blockIdx.x, tid = threadIdx.x;
     const int npix = d.E * A;
-    unsigned *img = reinterpret_cast<unsigned *>(lds);
-    if (src_u32) {
-        const unsigned *g = src_u32 + (long long)c * npix;
-        for (int i = tid; i < npix; i += NT) img[i] = g[i];
-    } else {
-        const float *g = src_f32 + (long long)c * npix;
-        for (int i = tid; i < npix; i += NT) img[i] = __float_as_uint(g[i]);
+    {
+        // 16-byte loads, all issued before the LDS stores (rows are 1 440 B, images 16-B aligned)
+        const f32x4 *g = src_u32 ? reinterpret_cast<const f32x4 *>(src_u32 + (long long)c * npix)
+                                 : reinterpret_cast<const f32x4 *>(src_f32 + (long long)c * npix);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+        const int nvec = npix / 4;
+        for (int base = 0; base < nvec; base += NT * 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NT + tid;
+                if (i < nvec) v[u] = g[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NT + tid;
+                if (i < nvec) dst[i] = v[u];
+            }
+        }
     }
     __syncthreads();
     const long long D = (long long)d.R * d.B;
@@ -512,13 +620,19 @@ constexpr int FUSED_U = 4;           // float4 loads in flight per thread
 constexpr int SPLIT_MIN_PTS = 16384; // a part must amortise its 5 760-pixel LDS init + flush
 constexpr int SPLIT_TARGET_WGS = 512;
 
+int tune_env(const char *name, int def)
+{
+    const char *v = getenv(name);   // development knob; unset in production
+    return v ? atoi(v) : def;
+}
+
 int check_params(const NscEncParams *p)
 {
     if (!p) return NSC_EINVAL;
     if (p->n_azimuth != A) return NSC_EUNSUPPORTED;
     if (p->n_elevation < 1 || p->n_elevation > MAXE) return NSC_EUNSUPPORTED;
     if (p->target_rows < 1 || p->target_rows > MAXR) return NSC_EUNSUPPORTED;
-    if (p->n_bins < 1 || p->n_bins > F) return NSC_EUNSUPPORTED;
+    if (p->n_bins < 1 || p->n_bins > MAXB) return NSC_EUNSUPPORTED;
     if (!(p->elev_max_rad > p->elev_min_rad)) return NSC_EINVAL;
     return NSC_OK;
 }
@@ -533,11 +647,14 @@ EncDev make_dev(const NscEncParams *p, int rows_in)
     d.B = p->n_bins;
     d.eps = p->epsilon;
     d.interp = p->interpolate;
+    d.dev_skip_finish = tune_env("NSC_TUNE_SKIP_FINISH", 0);
     return d;
 }
 
 int split_parts(int32_t n_clouds, int64_t total_points)
 {
+    const int force = tune_env("NSC_TUNE_SPLIT", 0);
+    if (force > 0) return force;
     if (n_clouds <= 0 || n_clouds >= SPLIT_TARGET_WGS) return 1;
     const int64_t avg = total_points / n_clouds;
     int64_t by_size = avg / SPLIT_MIN_PTS;
@@ -567,7 +684,7 @@ const char *nsc_status_string(int s)
     switch (s) {
     case NSC_OK: return "ok";
     case NSC_EINVAL: return "invalid argument";
-    case NSC_EUNSUPPORTED: return "unsupported shape (n_azimuth must be 360, rows <= 64, target_rows <= 16, n_bins <= 181)";
+    case NSC_EUNSUPPORTED: return "unsupported shape (n_azimuth must be 360, rows <= 64, target_rows <= 16, n_bins <= 176)";
     case NSC_EWORKSPACE: return "workspace too small";
     case NSC_ELAUNCH: return "kernel launch failed";
     default: return "unknown status";
@@ -615,10 +732,25 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
     const long long *off = reinterpret_cast<const long long *>(cloud_offsets);
 
     if (parts <= 1) {
-        auto k = encode_fused_kernel<FUSED_NW, FUSED_U>;
-        if ((st = set_lds(k, lp.total)) != NSC_OK) return st;
-        hipLaunchKernelGGL(k, dim3(n_clouds), dim3(FUSED_NW * 64), lp.total, stream, pts, off, stride, d,
-                           lut, out_desc, out_raw, out_interp);
+        const int variant = tune_env("NSC_TUNE_VARIANT", 0);
+#define NSC_LAUNCH_FUSED(NW_, U_, MINW_)                                                              \
+    {                                                                                                 \
+        auto k = encode_fused_kernel<NW_, U_, MINW_>;                                                 \
+        const LdsPlan lpv = lds_plan(d.E, d.R, d.B, NW_);                                             \
+        if ((st = set_lds(k, lpv.total)) != NSC_OK) return st;                                        \
+        hipLaunchKernelGGL(k, dim3(n_clouds), dim3(NW_ * 64), lpv.total, stream, pts, off, stride, d, \
+                           lut, out_desc, out_raw, out_interp);                                       \
+    }
+        switch (variant) {
+        case 1: NSC_LAUNCH_FUSED(4, 4, 4) break;
+        case 2: NSC_LAUNCH_FUSED(4, 8, 4) break;
+        case 3: NSC_LAUNCH_FUSED(8, 8, 4) break;
+        case 4: NSC_LAUNCH_FUSED(16, 4, 2) break;
+        case 5: NSC_LAUNCH_FUSED(4, 16, 4) break;
+        case 6: NSC_LAUNCH_FUSED(8, 4, 4) break;
+        case 7: NSC_LAUNCH_FUSED(4, 2, 4) break;
+        default: NSC_LAUNCH_FUSED(8, 4, 4) break;
+        }
     } else {
         const size_t need = (size_t)n_clouds * d.E * A * sizeof(unsigned);
         if (!ws || ws_bytes < need) return NSC_EWORKSPACE;

@@ -1,0 +1,238 @@
+"""SpectralGNN on MI355X -- drop-in for the reference's src/gnn/model.py.
+
+Same classes, constructor arguments, state-dict keys and ``forward(data)`` contract
+(model.py:21-205 SpectralGNN, :208-281 LocalUpdateGNN, :284-324 create_spectral_gnn).  The forward
+pass is one call into the C ABI (nsc_gat_forward, csrc/nsc_gat.hip): f32-MFMA projection GEMMs with
+fused BatchNorm/ReLU/residual epilogues and a wavefront-per-node attention/aggregation kernel.
+The module must live on a HIP device; there is no CPU fallback.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .gat_conv import GATConv
+
+_WS = {}
+
+
+def _ws(device, nbytes, tag):
+    key = (str(device), tag)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
+class GraphCSR:
+    """Device CSR-by-target arrays of one graph (built by nsc_graph_build_csr, cached per graph)."""
+
+    def __init__(self, edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], n_nodes: int):
+        dev = edge_index.device
+        _lib.require_cuda(edge_index, "data.edge_index")
+        L = _lib.lib()
+        ei = edge_index.to(torch.int64).contiguous()
+        E = int(ei.shape[1])
+        self.n_nodes, self.n_edges = n_nodes, E
+        self.capacity = E + n_nodes
+        self.row_ptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        self.src = torch.empty(self.capacity, dtype=torch.int32, device=dev)
+        self.eid = torch.empty(self.capacity, dtype=torch.int32, device=dev)
+        self.edge_dim = 0
+        self.loop_attr = None
+        ea = None
+        if edge_attr is not None:
+            ea = edge_attr.to(device=dev, dtype=torch.float32).contiguous()
+            if ea.dim() == 1:
+                ea = ea.unsqueeze(1)
+            self.edge_dim = int(ea.shape[1])
+            self.loop_attr = torch.empty((n_nodes, self.edge_dim), dtype=torch.float32, device=dev)
+        self.edge_attr = ea
+        nbytes = L.nsc_graph_workspace_bytes(n_nodes, E)
+        ws = _ws(dev, nbytes, "graph")
+        with torch.cuda.device(dev):
+            st = L.nsc_graph_build_csr(_lib.ptr(ei), E, n_nodes, _lib.ptr(ea), self.edge_dim,
+                                       _lib.ptr(self.row_ptr), _lib.ptr(self.src), _lib.ptr(self.eid),
+                                       _lib.ptr(self.loop_attr), _lib.ptr(ws), nbytes,
+                                       _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_graph_build_csr")
+
+    def struct(self) -> _lib.Graph:
+        g = _lib.Graph()
+        g.n_nodes = self.n_nodes
+        g.nnz = self.capacity
+        g.row_ptr = self.row_ptr.data_ptr()
+        g.src = self.src.data_ptr()
+        g.eid = self.eid.data_ptr()
+        g.loop_attr = self.loop_attr.data_ptr() if self.loop_attr is not None else None
+        return g
+
+
+class SpectralGNN(nn.Module):
+    """Input(800) -> Proj(256) -> GAT x3 (256) -> Proj(800) -> Output(800)   (model.py:21-94)"""
+
+    def __init__(self, input_dim: int = 800, hidden_dim: int = 256, output_dim: int = 800,
+                 n_layers: int = 3, n_heads: int = 1, dropout: float = 0.1, residual: bool = True,
+                 edge_dim: int = None):
+        super().__init__()
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.n_layers, self.n_heads, self.dropout = n_layers, n_heads, dropout
+        self.residual, self.edge_dim = residual, edge_dim
+        self.input_proj = nn.Linear(input_dim, hidden_dim)                   # :67
+        self.input_norm = nn.BatchNorm1d(hidden_dim)                         # :68
+        self.convs = nn.ModuleList()
+        self.batch_norms = nn.ModuleList()
+        for _ in range(n_layers):                                            # :74-85
+            self.convs.append(GATConv(hidden_dim, hidden_dim, heads=n_heads, concat=False,
+                                      dropout=dropout, edge_dim=edge_dim))
+            self.batch_norms.append(nn.BatchNorm1d(hidden_dim))
+        self.output_proj = nn.Linear(hidden_dim, output_dim)                 # :88
+        if residual and input_dim != output_dim:                             # :91-94
+            self.residual_proj = nn.Linear(input_dim, output_dim)
+        else:
+            self.residual_proj = None
+        self._csr_cache = {}
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _csr(self, data, use_edge_attr: bool) -> GraphCSR:
+        ei = data.edge_index
+        ea = getattr(data, "edge_attr", None) if use_edge_attr else None
+        n = int(data.x.shape[0])
+        key = (ei.data_ptr(), ei._version, tuple(ei.shape), n,
+               None if ea is None else (ea.data_ptr(), ea._version, tuple(ea.shape)))
+        csr = self._csr_cache.get(key)
+        if csr is None:
+            if len(self._csr_cache) >= 8:
+                self._csr_cache.clear()
+            csr = GraphCSR(ei, ea, n)
+            csr._keepalive = (ei, ea)        # pointers in the key stay valid while cached
+            self._csr_cache[key] = csr
+        return csr
+
+    @staticmethod
+    def _p(t):
+        if t is None:
+            return None
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.NscError("GNN parameters must be contiguous float32 tensors on the HIP device")
+        return t.data_ptr()
+
+    def _model_struct(self) -> _lib.GatModel:
+        m = _lib.GatModel()
+        m.in_dim, m.hidden, m.out_dim = self.input_dim, self.hidden_dim, self.output_dim
+        m.n_layers = self.n_layers
+        m.edge_dim = self.edge_dim or 0
+        m.residual = int(bool(self.residual))
+        m.bn_eps = float(self.input_norm.eps)
+        m.negative_slope = float(self.convs[0].negative_slope)
+        p = self._p
+        m.in_w, m.in_b = p(self.input_proj.weight), p(self.input_proj.bias)
+        bn = self.input_norm
+        m.in_bn_w, m.in_bn_b = p(bn.weight), p(bn.bias)
+        m.in_bn_mean, m.in_bn_var = p(bn.running_mean), p(bn.running_var)
+        m.out_w, m.out_b = p(self.output_proj.weight), p(self.output_proj.bias)
+        if self.residual_proj is not None:
+            m.res_w, m.res_b = p(self.residual_proj.weight), p(self.residual_proj.bias)
+        for l, (conv, bn) in enumerate(zip(self.convs, self.batch_norms)):
+            ly = m.layers[l]
+            ly.lin_w = p(conv.lin_src.weight)
+            ly.att_src, ly.att_dst = p(conv.att_src), p(conv.att_dst)
+            if conv.lin_edge is not None:
+                ly.lin_edge_w, ly.att_edge = p(conv.lin_edge.weight), p(conv.att_edge)
+            ly.bias = p(conv.bias)
+            ly.bn_w, ly.bn_b = p(bn.weight), p(bn.bias)
+            ly.bn_mean, ly.bn_var = p(bn.running_mean), p(bn.running_var)
+        return m
+
+    def _run(self, data, use_edge_attr: bool, want_alpha: bool):
+        x = data.x
+        _lib.require_cuda(x, "data.x")
+        if self.input_proj.weight.device != x.device:
+            raise _lib.NscError("SpectralGNN and data must be on the same HIP device")
+        if self.training:
+            raise NotImplementedError(
+                "training-mode forward (batch-stat BatchNorm, dropout, autograd) is not on the MI355X "
+                "path yet; call model.eval() for the inference forward (pipeline.py:253-256)")
+        dev = x.device
+        x = x.detach().to(torch.float32).contiguous()
+        n = int(x.shape[0])
+        csr = self._csr(data, use_edge_attr)
+        L = _lib.lib()
+        m = self._model_struct()
+        g = csr.struct()
+        out = torch.empty((n, self.output_dim), dtype=torch.float32, device=dev)
+        alpha = (torch.zeros((self.n_layers, csr.capacity), dtype=torch.float32, device=dev)
+                 if want_alpha else None)
+        nbytes = L.nsc_gat_workspace_bytes(C.byref(m), n)
+        ws = _ws(dev, nbytes, "gat")
+        with torch.cuda.device(dev):
+            st = L.nsc_gat_forward(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
+                                   _lib.ptr(out), _lib.ptr(alpha), _lib.ptr(ws), nbytes,
+                                   _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_gat_forward")
+        return out, alpha, csr
+
+    # -- reference API ----------------------------------------------------------------------
+    def forward(self, data) -> torch.Tensor:
+        """model.py:96-153: data.x (N,in), data.edge_index (2,E), optional data.edge_attr (E,edge_dim)."""
+        edge_attr = getattr(data, 'edge_attr', None)
+        use_edge = edge_attr is not None and self.edge_dim is not None       # :126
+        out, _, _ = self._run(data, use_edge, False)
+        return out
+
+    def forward_with_attention(self, data) -> tuple:
+        """model.py:155-201: convs are called WITHOUT edge_attr there; returns
+        (embeddings, [(edge_index_with_self_loops (2,E'), alpha (E',1))] * n_layers) in PyG's
+        order (kept edges in input order, then the N self loops)."""
+        out, alpha, csr = self._run(data, False, True)
+        nnz = int(csr.row_ptr[-1].item())
+        eid = csr.eid[:nnz].long()
+        ei = data.edge_index
+        keep = ei[0] != ei[1]
+        rank = torch.cumsum(keep.long(), 0) - 1                              # position among kept edges
+        n_kept = int(keep.sum().item())
+        tgt = torch.repeat_interleave(torch.arange(csr.n_nodes, device=ei.device),
+                                      (csr.row_ptr[1:] - csr.row_ptr[:-1]).long())
+        pos = torch.where(eid >= 0, rank[eid.clamp(min=0)], n_kept + tgt)
+        loops = torch.arange(csr.n_nodes, device=ei.device)
+        ei_full = torch.cat([ei[:, keep], torch.stack([loops, loops])], 1)
+        weights = []
+        for l in range(self.n_layers):
+            a = torch.empty(nnz, dtype=torch.float32, device=ei.device)
+            a[pos] = alpha[l, :nnz]
+            weights.append((ei_full, a.unsqueeze(1)))
+        return out, weights
+
+    def get_embedding_dim(self) -> int:
+        return self.output_dim
+
+
+class LocalUpdateGNN(nn.Module):
+    """model.py:208-281: wrapper whose local update is a stub in the reference -- always full graph."""
+
+    def __init__(self, gnn: SpectralGNN, k_hops: int = 3):
+        super().__init__()
+        self.gnn = gnn
+        self.k_hops = k_hops
+
+    def forward(self, data, update_nodes: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.gnn(data)                                                # :248-255
+
+    def forward_local(self, data, center_node: int, k_hops: Optional[int] = None) -> torch.Tensor:
+        embeddings = self.gnn(data)                                          # :277-281
+        return embeddings[center_node:center_node + 1]
+
+
+def create_spectral_gnn(input_dim: int = 800, hidden_dim: int = 256, output_dim: int = 800,
+                        n_layers: int = 3, dropout: float = 0.1, use_local_updates: bool = True,
+                        local_update_hops: int = 3, edge_dim: int = None) -> nn.Module:
+    """model.py:284-324"""
+    base_gnn = SpectralGNN(input_dim=input_dim, hidden_dim=hidden_dim, output_dim=output_dim,
+                           n_layers=n_layers, n_heads=1, dropout=dropout, residual=True,
+                           edge_dim=edge_dim)
+    if use_local_updates:
+        return LocalUpdateGNN(base_gnn, k_hops=local_update_hops)
+    return base_gnn

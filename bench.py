@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the descriptor hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input PER RANK:
+    1 024 clouds x 120 000 points (resident in HBM, 1.97 GB)
+      -> fused range-image / FFT / histogram encoder (nsc_encode_clouds)
+      -> [N > 1] RCCL all-gather of the (1 024, 800) descriptor shards
+      -> 3-layer GAT forward over the rank's keyframe range + 6-node halo (nsc_gat_forward)
+Work per GPU is fixed as N grows (weak scaling); value = N * 1 024 * K / max-over-ranks time.
+
+For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+N_CLOUDS = 1024          # BASELINE.json configs[1]: batch of 1024 synthetic clouds
+N_POINTS = 120000        # 120k-pt clouds
+BYTES_PER_CLOUD = 16 * N_POINTS + 3200     # algorithmic bytes of the fused encoder
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
+
+
+def cpu_baseline(pts_dev, off_dev, model, n_sample):
+    """Oracle ("port") on the host cores: encode n_sample clouds of the SAME workload with the C
+    restatement (pthreads, all cores) + the torch-CPU GAT restatement on an n_sample-node chain."""
+    import nsc_oracle as orc
+    import gat_oracle as go
+    from neural_spectral_codec_amd.keyframe import graph_manager as gm
+    from neural_spectral_codec_amd import synth
+    cores = os.cpu_count() or 1
+    pts = pts_dev[: n_sample * N_POINTS].cpu().numpy()
+    off = off_dev[: n_sample + 1].cpu().numpy()
+    orc.encode_clouds(pts[: 4 * N_POINTS], off[:5], n_threads=min(4, cores))       # warm
+    t0 = time.perf_counter()
+    desc = orc.encode_clouds(pts, off, n_threads=cores)
+    t_enc = time.perf_counter() - t0
+    torch.set_num_threads(cores)
+    import copy
+    model = copy.deepcopy(model).cpu()
+    g = gm.build_chain_graph(torch.from_numpy(desc), 5, "cpu", synth.make_pose_chain(n_sample, 0))
+    go.forward_reference(model, g)                                                   # warm
+    t0 = time.perf_counter()
+    go.forward_reference(model, g)
+    t_gat = time.perf_counter() - t0
+    return {
+        "value": n_sample / (t_enc + t_gat), "unit": "keyframes/s", "cores": cores, "kind": "port",
+        "sample": f"{n_sample} of the {N_CLOUDS} x {N_POINTS}-point clouds of this run: oracle/nsc_oracle.c "
+                  f"on {cores} threads ({t_enc:.2f} s) + torch-CPU GAT restatement on a {n_sample}-node "
+                  f"chain ({t_gat * 1e3:.1f} ms)",
+    }, desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--clouds", type=int, default=N_CLOUDS, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-sample", type=int, default=256, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from neural_spectral_codec_amd import synth
+    from neural_spectral_codec_amd import distributed as nd
+    from neural_spectral_codec_amd.encoding import SpectralEncoder
+    from neural_spectral_codec_amd.gnn.model import create_spectral_gnn
+    import gat_oracle as go
+
+    n_local = args.clouds
+    n_total = n_local * world
+    enc = SpectralEncoder(n_elevation=16, n_azimuth=360, n_bins=50, alpha=2.0,
+                          target_elevation_bins=16).to(dev)
+    torch.manual_seed(0)                                    # identical random-init weights on all ranks
+    model = create_spectral_gnn(input_dim=800, hidden_dim=256, output_dim=800, n_layers=3,
+                                dropout=0.1, edge_dim=2)
+    go.randomize_bn_stats(model)
+    model = model.to(dev).eval()
+    pts, off = synth.make_clouds_device(n_local, N_POINTS, dev, seed=1234 + rank)
+    poses = synth.make_pose_chain(n_total, 0)
+    path = nd.ShardedDescriptorPath(enc, model, n_total, poses)
+
+    desc_local = torch.empty((n_local, 800), dtype=torch.float32, device=dev)
+
+    class _Enc:                                             # encode into a fixed output buffer
+        @staticmethod
+        def encode_points_batch(clouds):
+            return enc.encode_points_batch(clouds, out=desc_local)
+    path.encoder = _Enc
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):                # the first step also builds the cached graph
+            path.step((pts, off))
+        sync()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            # the encoder kernel is bracketed by HIP events on the stream it is launched on (torch's
+            # current stream) -> live per-launch duration for the roofline object
+            ev[k][0].record()
+            local = _Enc.encode_points_batch((pts, off))
+            ev[k][1].record()
+            desc_all = nd.all_gather_descriptors(local, n_total)
+            path._graph.x = desc_all[path._wlo:path._wlo + path._graph.num_nodes]
+            emb = model(path._graph)
+        sync()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank == 0:
+        value = n_total * args.steps / dt
+        achieved = n_local * BYTES_PER_CLOUD / (enc_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "encoder_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds",
+            "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{n_local} clouds x {N_POINTS} points per GPU (BASELINE.json configs[1]) "
+                            f"+ 3-layer GAT forward over the {n_local}-keyframe temporal chain "
+                            f"(5 temporal neighbours, edge_dim=2, eval mode)"
+                            + (f", RCCL all-gather of {world} x ({n_local},800) f32 descriptor shards"
+                               if world > 1 else ""),
+                "clouds_per_gpu": n_local, "points_per_cloud": N_POINTS, "descriptor_dim": 800,
+                "gat": "800->256->GATx3->800", "parallelism": f"keyframe-shard x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "encode_fused_kernel", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "launch_ms": enc_ms,
+                "algorithmic_bytes_per_launch": n_local * BYTES_PER_CLOUD,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, odesc = cpu_baseline(pts, off, model, min(args.cpu_sample, n_local))
+            line["cpu_baseline"] = cb
+            # parity gate next to the number: sample of this run's descriptors vs the oracle
+            got = desc_local[: odesc.shape[0]].cpu().numpy()
+            line["parity"] = {
+                "descriptor_max_abs_err_vs_oracle": float(np.abs(got - odesc).max()),
+                "ok": bool(np.all(np.abs(got - odesc) <= 1e-6 * np.abs(odesc) + 1e-9)),
+            }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,7 @@ const char *nsc_status_string(int status);
 typedef struct NscEncParams {
     int32_t n_elevation;   /* projector rows E: 1..64          range_image.py:104              */
     int32_t n_azimuth;     /* projector cols A: must be 360    range_image.py:105              */
-    int32_t n_bins;        /* histogram bins per row, 1..181   spectral_encoder.py:39          */
+    int32_t n_bins;        /* histogram bins per row, 1..176   spectral_encoder.py:39          */
     int32_t target_rows;   /* target_elevation_bins R, 1..16   spectral_encoder.py:43          */
     double  elev_min_rad;  /* np.deg2rad(elevation_range[0])   range_image.py:126              */
     double  elev_max_rad;  /* np.deg2rad(elevation_range[1])   range_image.py:127              */
@@ -115,8 +115,8 @@ typedef struct NscGatLayer {      /* device pointers; names are the reference's 
 } NscGatLayer;
 
 typedef struct NscGatModel {
-    int32_t in_dim;               /* 800   model.py:33 */
-    int32_t hidden;               /* 256   model.py:34 (multiple of 4, <= 1024) */
+    int32_t in_dim;               /* 800   model.py:33 (multiple of 16) */
+    int32_t hidden;               /* 256   model.py:34 (multiple of 16, <= 1024) */
     int32_t out_dim;              /* 800   model.py:35 */
     int32_t n_layers;             /* 3     model.py:36 */
     int32_t edge_dim;             /* 0 = GATConv built without edge_dim (pipeline.py:158-166) */
@@ -127,6 +127,7 @@ typedef struct NscGatModel {
     const float *in_bn_w, *in_bn_b, *in_bn_mean, *in_bn_var;   /* input_norm.* model.py:68 */
     const float *out_w, *out_b;   /* output_proj.{weight (out,H), bias (out)}  model.py:88 */
     const float *res_w, *res_b;   /* residual_proj.* (out,in) or NULL when in_dim == out_dim (model.py:91-94) */
+    const float *folded;          /* nsc_gat_fold_weights() output, nsc_gat_folded_floats() floats */
     NscGatLayer layers[NSC_GAT_MAX_LAYERS];
 } NscGatModel;
 
@@ -134,7 +135,7 @@ typedef struct NscGatModel {
  * one loop per node appended last, its edge attribute = mean of the node's incoming edge attributes). */
 typedef struct NscGraph {
     int32_t n_nodes;
-    int32_t nnz;                  /* kept edges + n_nodes self loops */
+    int32_t nnz;                  /* capacity of src/eid = E + n_nodes (stride of alpha_out layers) */
     const int32_t *row_ptr;       /* (n_nodes+1) */
     const int32_t *src;           /* (nnz) source node of each entry, entries of a target in edge order */
     const int32_t *eid;           /* (nnz) index into the caller's edge list, -1 for the self loop */
@@ -144,11 +145,17 @@ typedef struct NscGraph {
 size_t nsc_graph_workspace_bytes(int32_t n_nodes, int64_t n_edges);
 
 /* edge_index (2,E) int64 [row 0 = source j, row 1 = target i] -> CSR arrays (caller-allocated:
- * row_ptr n_nodes+1, src/eid E+n_nodes, loop_attr n_nodes*edge_dim).  nnz_out (device int32) receives
- * row_ptr[n_nodes].  Edges with an endpoint outside [0,n_nodes) are dropped. */
+ * row_ptr n_nodes+1, src/eid E+n_nodes, loop_attr n_nodes*edge_dim); row_ptr[n_nodes] is the entry
+ * count.  Edges with an endpoint outside [0,n_nodes) are dropped. */
 int nsc_graph_build_csr(const int64_t *edge_index, int64_t n_edges, int32_t n_nodes,
                         const float *edge_attr, int32_t edge_dim, int32_t *row_ptr, int32_t *src,
                         int32_t *eid, float *loop_attr, void *ws, size_t ws_bytes, void *stream);
+
+/* Weights-only folding, redone only when the GATConv parameters change: per layer
+ * u_src = W^T att_src, u_dst = W^T att_dst (the attention dot products then ride along the lin GEMM as
+ * two extra output columns) and v = W_edge^T att_edge (the edge term becomes an edge_dim-long dot). */
+size_t nsc_gat_folded_floats(const NscGatModel *m);
+int    nsc_gat_fold_weights(const NscGatModel *m, float *folded, void *stream);
 
 size_t nsc_gat_workspace_bytes(const NscGatModel *m, int32_t n_nodes);
 

@@ -43,6 +43,7 @@ class GatModel(C.Structure):
         ("in_w", C.c_void_p), ("in_b", C.c_void_p),
         ("in_bn_w", C.c_void_p), ("in_bn_b", C.c_void_p), ("in_bn_mean", C.c_void_p), ("in_bn_var", C.c_void_p),
         ("out_w", C.c_void_p), ("out_b", C.c_void_p), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
+        ("folded", C.c_void_p),
         ("layers", GatLayer * GAT_MAX_LAYERS),
     ]
 
@@ -68,6 +69,8 @@ SYMBOLS = {
     "nsc_debug_point_bins": (C.c_int, [_vp, _i64, _i32, _pp, _vp, _vp, _vp]),
     "nsc_graph_workspace_bytes": (_sz, [_i32, _i64]),
     "nsc_graph_build_csr": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_gat_folded_floats": (_sz, [C.POINTER(GatModel)]),
+    "nsc_gat_fold_weights": (C.c_int, [C.POINTER(GatModel), _vp, _vp]),
     "nsc_gat_workspace_bytes": (_sz, [C.POINTER(GatModel), _i32]),
     "nsc_gat_forward": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -121,18 +121,23 @@ struct PrepArgs {
     int H, edge_dim;
 };
 
-// grid (n_layers, 3): y = 0 -> u_src, 1 -> u_dst, 2 -> v.  aux layout per layer: [u_src H][u_dst H][v 8]
-__global__ __launch_bounds__(256) void gat_prepare_kernel(PrepArgs a, float *__restrict__ aux)
+// grid (n_layers, 3): y = 0 -> u_src, 1 -> u_dst, 2 -> v.  folded layout per layer: [u_src H][u_dst H][v 8]
+__global__ __launch_bounds__(256) void gat_fold_kernel(PrepArgs a, float *__restrict__ folded)
 {
     const int l = blockIdx.x, which = blockIdx.y, H = a.H;
-    float *dst = aux + (long long)l * (2 * H + NSC_GAT_MAX_EDGE_DIM);
+    float *dst = folded + (long long)l * (2 * H + NSC_GAT_MAX_EDGE_DIM);
     if (which < 2) {
         const float *att = which == 0 ? a.l[l].att_src : a.l[l].att_dst;
         const float *w = a.l[l].w;
-        for (int k = threadIdx.x; k < H; k += 256) {
-            float s = 0.0f;
-            for (int c = 0; c < H; ++c) s = __builtin_fmaf(w[(long long)c * H + k], att[c], s);
-            dst[which * H + k] = s;
+        for (int k = threadIdx.x; k < H; k += 256) {          // coalesced over k, 8 rows in flight
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int c = 0;
+            for (; c + 8 <= H; c += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] = __builtin_fmaf(w[(long long)(c + u) * H + k], att[c + u], s[u]);
+            }
+            for (; c < H; ++c) s[0] = __builtin_fmaf(w[(long long)c * H + k], att[c], s[0]);
+            dst[which * H + k] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
         }
     } else if (threadIdx.x < NSC_GAT_MAX_EDGE_DIM) {
         const int d = threadIdx.x;
@@ -160,69 +165,143 @@ struct GemmEpi {
     float *aux0, *aux1;                             // columns n_main, n_main+1 (M each), nullable
 };
 
+// EPI: 0 = plain store + aux columns (lin), 1 = bias + BatchNorm + ReLU (input_proj),
+//      2 = bias + residual (output_proj / residual_proj)
+// Tiles of A (16*ACC x 64) and B (64 x 64) are staged through LDS: global loads are 256-byte row
+// segments (16 lanes x 16 B), each element is fetched once per workgroup, and the MFMA operands are
+// ds_read_b128 from rows padded to 68 floats.  Two LDS stages: the next chunk's global loads are in
+// flight while the current chunk's MFMAs run.
+template <int ACC, int EPI>   // ACC accumulators of 16 rows each per wave: workgroup tile (16*ACC) x 64
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ A, int lda,
                                                       const float *__restrict__ B, int ldb,
                                                       const float *__restrict__ Bx, int M, int N,
                                                       int n_main, int K, float *__restrict__ C, int ldc,
                                                       GemmEpi ep)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64 + wave * 16;
-    const int ra0 = m0 + r, ra1 = m0 + 16 + r, cb = n0 + r;
-    const bool va0 = ra0 < M, va1 = ra1 < M, vb = cb < N;
-    const float *pa0 = A + (long long)(va0 ? ra0 : 0) * lda + 4 * q;
-    const float *pa1 = A + (long long)(va1 ? ra1 : 0) * lda + 4 * q;
-    const float *pb = (cb < n_main) ? B + (long long)cb * ldb + 4 * q
-                                    : Bx + (long long)((vb ? cb : n_main) - n_main) * ldb + 4 * q;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc0 = zero, acc1 = zero;
+    constexpr int BM = 16 * ACC, BN = 64, BK = 64, LD = BK + 4;
+    constexpr int NA = BM * (BK / 4) / 256;    // float4 loads per thread for the A tile (1 or 2)
+    constexpr int NB = BN * (BK / 4) / 256;    // 4
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
 
-    auto ld = [&](const float *p, bool ok, int kb) -> f32x4 {
-        return (ok && kb + 4 * q + 3 < K) ? *reinterpret_cast<const f32x4 *>(p + kb) : zero;
-    };
-    f32x4 a0 = ld(pa0, va0, 0), a1 = ld(pa1, va1, 0), b = ld(pb, vb, 0);
-    for (int kb = 0; kb < K; kb += 16) {
-        const f32x4 na0 = ld(pa0, va0, kb + 16), na1 = ld(pa1, va1, kb + 16), nb = ld(pb, vb, kb + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int cb = n0 + wave * 16 + r;
+
+    // staging map: float4 f = tid + 256 i -> tile row f / 16, k offset 4 (f % 16).  Rows / columns
+    // past the matrix re-read a valid row: their products only reach outputs that are never stored.
+    const float *ga[NA];
+    int sa[NA];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b[t], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b[t], acc1, 0, 0, 0);
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i, row = f >> 4, c4 = f & 15;
+        const int gr = m0 + row;
+        ga[i] = A + (long long)(gr < M ? gr : M - 1) * lda + 4 * c4;
+        sa[i] = row * LD + 4 * c4;
+    }
+    const float *gb[NB];
+    int sb[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = tid + 256 * i, row = f >> 4, c4 = f & 15;
+        int gc = n0 + row;
+        gc = gc < N ? gc : N - 1;
+        gb[i] = ((gc < n_main) ? B + (long long)gc * ldb : Bx + (long long)(gc - n_main) * ldb) + 4 * c4;
+        sb[i] = row * LD + 4 * c4;
+    }
+
+    // epilogue operands of this lane's column, fetched up front (off the critical path)
+    const int col = cb < N ? cb : N - 1;
+    float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
+    if (EPI != 0) bias = ep.bias[col];
+    if (EPI == 1) {
+        // torch batch_norm eval: alpha = invstd * weight, beta = bias - mean * alpha
+        const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
+        bn_scale = invstd * ep.bn_w[col];
+        bn_shift = ep.bn_b[col] - ep.bn_mean[col] * bn_scale;
+    }
+
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[ACC];
+#pragma unroll
+    for (int h = 0; h < ACC; ++h) acc[h] = zero;
+
+    f32x4 ra[NA], rb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(gb[i]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[0][sa[i]]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[0][sb[i]]) = rb[i];
+    __syncthreads();
+
+    const int nchunks = K / BK + ((K % BK) ? 1 : 0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        const int kn = (ch + 1) * BK;                      // next chunk (K is a multiple of 16)
+        const bool more = ch + 1 < nchunks;
+        if (more) {
+            // a short last chunk (K % 64 != 0) re-reads valid columns; those k-blocks are skipped below
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int c4 = (tid + 256 * i) & 15;
+                const int k = kn + 4 * c4;
+                ra[i] = *reinterpret_cast<const f32x4 *>(ga[i] + (k + 4 <= K ? kn : K - 4 - 4 * c4));
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int c4 = (tid + 256 * i) & 15;
+                const int k = kn + 4 * c4;
+                rb[i] = *reinterpret_cast<const f32x4 *>(gb[i] + (k + 4 <= K ? kn : K - 4 - 4 * c4));
+            }
         }
-        a0 = na0; a1 = na1; b = nb;
+        const float *as = As[cur], *bs = Bs[cur];
+        const int kleft = K - ch * BK;
+#pragma unroll
+        for (int d = 0; d < BK / 16; ++d) {
+            if (16 * d < kleft) {                          // wave-uniform
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
+                f32x4 av[ACC];
+#pragma unroll
+                for (int h = 0; h < ACC; ++h)
+                    av[h] = *reinterpret_cast<const f32x4 *>(&as[(16 * h + r) * LD + 16 * d + 4 * q]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int h = 0; h < ACC; ++h)
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[cur ^ 1][sa[i]]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[cur ^ 1][sb[i]]) = rb[i];
+        }
+        __syncthreads();
     }
 
     // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
-    const int col = n0 + r;
-    if (col >= N) return;
-    float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
-    const bool main_col = col < n_main;
-    if (main_col) {
-        if (ep.bias) bias = ep.bias[col];
-        if (ep.bn_w) {
-            // torch batch_norm eval: alpha = invstd * weight, beta = bias - mean * alpha
-            const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
-            bn_scale = invstd * ep.bn_w[col];
-            bn_shift = ep.bn_b[col] - ep.bn_mean[col] * bn_scale;
-        }
-    }
+    if (cb >= N) return;
+    const bool main_col = cb < n_main;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const f32x4 acc = h ? acc1 : acc0;
+    for (int h = 0; h < ACC; ++h) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = m0 + 16 * h + 4 * q + reg;
             if (row >= M) continue;
-            float v = acc[reg];
+            float v = acc[h][reg];
             if (main_col) {
-                v = v + bias;
-                if (ep.bn_w) v = v * bn_scale + bn_shift;
-                if (ep.relu) v = fmaxf(v, 0.0f);
-                if (ep.resid) v = v + ep.resid[(long long)row * ep.ldr + col];
-                C[(long long)row * ldc + col] = v;
+                if (EPI != 0) v = v + bias;
+                if (EPI == 1) v = fmaxf(v * bn_scale + bn_shift, 0.0f);
+                if (EPI == 2 && ep.resid) v = v + ep.resid[(long long)row * ep.ldr + cb];
+                C[(long long)row * ldc + cb] = v;
             } else {
-                float *aux = (col == n_main) ? ep.aux0 : ep.aux1;
-                if (aux) aux[row] = v;
+                float *aux = (cb == n_main) ? ep.aux0 : ep.aux1;
+                aux[row] = v;
             }
         }
     }
@@ -283,39 +362,78 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
         return l > 0.0f ? l : a.slope * l;                        // leaky_relu
     };
 
-    float m = -INFINITY;
-    for (int e = beg + lane; e < end; e += 64) { int j; m = fmaxf(m, logit(e, j)); }
-    m = wave_max(m);
-    float s = 0.0f;
-    for (int e = beg + lane; e < end; e += 64) { int j; s += expf(logit(e, j) - m); }
-    s = wave_sumf(s);
-    const float den = s + 1e-16f;                                 // PyG softmax
-
     f32x4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c0 = beg; c0 < end; c0 += 64) {
-        const int e = c0 + lane;
+    const int deg = end - beg;
+
+    if (deg <= 64) {
+        // common case (temporal chain: deg <= 5): one logit per lane, everything stays in registers
+        const int e = beg + lane;
         int j = 0;
-        float al = 0.0f;
-        if (e < end) {
-            al = expf(logit(e, j) - m) / den;
-            if (a.alpha_out) a.alpha_out[e] = al;
-        }
-        const int cnt = min(64, end - c0);
-        for (int t = 0; t < cnt; ++t) {                           // entries in edge order, loop last
-            const float at = __shfl(al, t);
-            const int jt = __shfl(j, t);
-            const float *g = a.G + (long long)jt * a.H;
+        float l = -INFINITY;
+        if (e < end) l = logit(e, j);
+        const float m = wave_max(l);
+        const float p = (e < end) ? expf(l - m) : 0.0f;
+        const float den = wave_sumf(p) + 1e-16f;                  // PyG softmax
+        const float al = p / den;
+        if (a.alpha_out && e < end) a.alpha_out[e] = al;
+        for (int t0 = 0; t0 < deg; t0 += 8) {                     // 8 neighbour rows in flight
+            f32x4 gv[8][CH];
+            float at[8];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int col = 4 * lane + 256 * c;
-                if (col < a.H) {
-                    const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + col);
-                    acc[c].x = __builtin_fmaf(at, gv.x, acc[c].x);
-                    acc[c].y = __builtin_fmaf(at, gv.y, acc[c].y);
-                    acc[c].z = __builtin_fmaf(at, gv.z, acc[c].z);
-                    acc[c].w = __builtin_fmaf(at, gv.w, acc[c].w);
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u;
+                at[u] = (t < deg) ? __shfl(al, t & 63) : 0.0f;
+                const int jt = __shfl(j, t & 63);
+                const float *g = a.G + (long long)((t < deg) ? jt : i) * a.H;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int col = 4 * lane + 256 * c;
+                    gv[u][c] = (col < a.H) ? *reinterpret_cast<const f32x4 *>(g + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)                           // entries in edge order, loop last
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    acc[c].x = __builtin_fmaf(at[u], gv[u][c].x, acc[c].x);
+                    acc[c].y = __builtin_fmaf(at[u], gv[u][c].y, acc[c].y);
+                    acc[c].z = __builtin_fmaf(at[u], gv[u][c].z, acc[c].z);
+                    acc[c].w = __builtin_fmaf(at[u], gv[u][c].w, acc[c].w);
+                }
+        }
+    } else {
+        float m = -INFINITY;
+        for (int e = beg + lane; e < end; e += 64) { int j; m = fmaxf(m, logit(e, j)); }
+        m = wave_max(m);
+        float s = 0.0f;
+        for (int e = beg + lane; e < end; e += 64) { int j; s += expf(logit(e, j) - m); }
+        s = wave_sumf(s);
+        const float den = s + 1e-16f;
+        for (int c0 = beg; c0 < end; c0 += 64) {
+            const int e = c0 + lane;
+            int j = 0;
+            float al = 0.0f;
+            if (e < end) {
+                al = expf(logit(e, j) - m) / den;
+                if (a.alpha_out) a.alpha_out[e] = al;
+            }
+            const int cnt = min(64, end - c0);
+            for (int t = 0; t < cnt; ++t) {
+                const float at = __shfl(al, t);
+                const int jt = __shfl(j, t);
+                const float *g = a.G + (long long)jt * a.H;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int col = 4 * lane + 256 * c;
+                    if (col < a.H) {
+                        const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + col);
+                        acc[c].x = __builtin_fmaf(at, gv.x, acc[c].x);
+                        acc[c].y = __builtin_fmaf(at, gv.y, acc[c].y);
+                        acc[c].z = __builtin_fmaf(at, gv.z, acc[c].z);
+                        acc[c].w = __builtin_fmaf(at, gv.w, acc[c].w);
+                    }
                 }
             }
         }
@@ -348,7 +466,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GatWs {
-    size_t h0, h1, g, a_src, a_dst, aux, total;
+    size_t h0, h1, g, a_src, a_dst, total;
 };
 
 GatWs gat_ws(const NscGatModel *m, int N)
@@ -361,7 +479,6 @@ GatWs gat_ws(const NscGatModel *m, int N)
     w.g = o;  o += nh;
     w.a_src = o; o += align256((size_t)N * sizeof(float));
     w.a_dst = o; o += align256((size_t)N * sizeof(float));
-    w.aux = o; o += align256((size_t)m->n_layers * (2 * m->hidden + NSC_GAT_MAX_EDGE_DIM) * sizeof(float));
     w.total = o;
     return w;
 }
@@ -370,8 +487,9 @@ int check_model(const NscGatModel *m)
 {
     if (!m) return NSC_EINVAL;
     if (m->n_layers < 1 || m->n_layers > NSC_GAT_MAX_LAYERS) return NSC_EUNSUPPORTED;
-    if (m->hidden < 4 || m->hidden > 1024 || (m->hidden & 3)) return NSC_EUNSUPPORTED;
-    if (m->in_dim < 4 || (m->in_dim & 3) || m->out_dim < 1) return NSC_EUNSUPPORTED;
+    if (m->hidden < 16 || m->hidden > 1024 || (m->hidden & 15)) return NSC_EUNSUPPORTED;   // GEMM k-blocks of 16
+    if (m->in_dim < 16 || (m->in_dim & 15) || m->out_dim < 1) return NSC_EUNSUPPORTED;
+    if (!m->in_bn_w || !m->in_bn_b || !m->in_bn_mean || !m->in_bn_var) return NSC_EINVAL;
     if (m->edge_dim < 0 || m->edge_dim > NSC_GAT_MAX_EDGE_DIM) return NSC_EUNSUPPORTED;
     if (!m->in_w || !m->in_b || !m->out_w || !m->out_b) return NSC_EINVAL;
     if (m->residual && m->in_dim != m->out_dim && (!m->res_w || !m->res_b)) return NSC_EINVAL;
@@ -383,11 +501,22 @@ int check_model(const NscGatModel *m)
     return NSC_OK;
 }
 
+template <int EPI>
 void launch_gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, const float *Bx, int M,
                  int N, int n_main, int K, float *C, int ldc, const GemmEpi &ep)
 {
-    dim3 grid((N + 63) / 64, (M + 31) / 32);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep);
+    // two 16-row accumulators per wave share the B operand; with few row tiles use one so that
+    // every SIMD of the chip gets a wave (the GEMMs here are latency-, not throughput-bound)
+    const long long wgs2 = (long long)((N + 63) / 64) * ((M + 31) / 32);
+    if (wgs2 >= 384) {
+        dim3 grid((N + 63) / 64, (M + 31) / 32);
+        hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K,
+                           C, ldc, ep);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 15) / 16);
+        hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K,
+                           C, ldc, ep);
+    }
 }
 
 }  // namespace
@@ -429,6 +558,32 @@ int nsc_graph_build_csr(const int64_t *edge_index, int64_t E, int32_t N, const f
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 
+size_t nsc_gat_folded_floats(const NscGatModel *m)
+{
+    if (check_model(m) != NSC_OK) return 0;
+    return (size_t)m->n_layers * (2 * m->hidden + NSC_GAT_MAX_EDGE_DIM);
+}
+
+int nsc_gat_fold_weights(const NscGatModel *m, float *folded, void *stream_)
+{
+    int stt = check_model(m);
+    if (stt != NSC_OK) return stt;
+    if (!folded) return NSC_EINVAL;
+    PrepArgs pa;
+    pa.H = m->hidden;
+    pa.edge_dim = m->edge_dim;
+    for (int l = 0; l < m->n_layers; ++l) {
+        pa.l[l].w = m->layers[l].lin_w;
+        pa.l[l].att_src = m->layers[l].att_src;
+        pa.l[l].att_dst = m->layers[l].att_dst;
+        pa.l[l].w_edge = m->layers[l].lin_edge_w;
+        pa.l[l].att_edge = m->layers[l].att_edge;
+    }
+    hipLaunchKernelGGL(gat_fold_kernel, dim3(m->n_layers, 3), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       pa, folded);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
 size_t nsc_gat_workspace_bytes(const NscGatModel *m, int32_t n_nodes)
 {
     if (check_model(m) != NSC_OK || n_nodes <= 0) return 0;
@@ -443,7 +598,7 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     if (!g || g->n_nodes < 0) return NSC_EINVAL;
     const int N = g->n_nodes;
     if (N == 0) return NSC_OK;
-    if (!x || !out || !g->row_ptr || !g->src || !g->eid) return NSC_EINVAL;
+    if (!x || !out || !g->row_ptr || !g->src || !g->eid || !m->folded) return NSC_EINVAL;
     const GatWs w = gat_ws(m, N);
     if (!ws || ws_bytes < w.total) return NSC_EWORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream_);
@@ -451,21 +606,9 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     float *h0 = reinterpret_cast<float *>(base + w.h0), *h1 = reinterpret_cast<float *>(base + w.h1);
     float *G = reinterpret_cast<float *>(base + w.g);
     float *a_src = reinterpret_cast<float *>(base + w.a_src), *a_dst = reinterpret_cast<float *>(base + w.a_dst);
-    float *aux = reinterpret_cast<float *>(base + w.aux);
+    const float *aux = m->folded;
     const int H = m->hidden, L = m->n_layers;
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;      // model.py:126
-
-    PrepArgs pa;
-    pa.H = H;
-    pa.edge_dim = m->edge_dim;
-    for (int l = 0; l < L; ++l) {
-        pa.l[l].w = m->layers[l].lin_w;
-        pa.l[l].att_src = m->layers[l].att_src;
-        pa.l[l].att_dst = m->layers[l].att_dst;
-        pa.l[l].w_edge = m->layers[l].lin_edge_w;
-        pa.l[l].att_edge = m->layers[l].att_edge;
-    }
-    hipLaunchKernelGGL(gat_prepare_kernel, dim3(L, 3), dim3(256), 0, st, pa, aux);
 
     // input_proj + input_norm + relu                                       model.py:116-118
     GemmEpi ep = {};
@@ -473,17 +616,17 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     ep.bn_w = m->in_bn_w; ep.bn_b = m->in_bn_b; ep.bn_mean = m->in_bn_mean; ep.bn_var = m->in_bn_var;
     ep.bn_eps = m->bn_eps;
     ep.relu = 1;
-    launch_gemm(st, x, m->in_dim, m->in_w, m->in_dim, nullptr, N, H, H, m->in_dim, h0, H, ep);
+    launch_gemm<1>(st, x, m->in_dim, m->in_w, m->in_dim, nullptr, N, H, H, m->in_dim, h0, H, ep);
 
     float *cur = h0, *nxt = h1;
     for (int l = 0; l < L; ++l) {
         const NscGatLayer &Ly = m->layers[l];
-        float *auxl = aux + (size_t)l * (2 * H + NSC_GAT_MAX_EDGE_DIM);
+        const float *auxl = aux + (size_t)l * (2 * H + NSC_GAT_MAX_EDGE_DIM);
         // G = cur * W^T, plus a_src = cur . u_src and a_dst = cur . u_dst as columns H, H+1
         GemmEpi e2 = {};
         e2.aux0 = a_src;
         e2.aux1 = a_dst;
-        launch_gemm(st, cur, H, Ly.lin_w, H, auxl, N, H + 2, H, H, G, H, e2);
+        launch_gemm<0>(st, cur, H, Ly.lin_w, H, auxl, N, H + 2, H, H, G, H, e2);
 
         AggArgs a = {};
         a.row_ptr = g->row_ptr; a.src = g->src; a.eid = g->eid;
@@ -514,14 +657,14 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     GemmEpi e3 = {};
     e3.bias = m->out_b;
     if (m->residual && m->in_dim == m->out_dim) { e3.resid = x; e3.ldr = m->in_dim; }
-    launch_gemm(st, cur, H, m->out_w, H, nullptr, N, m->out_dim, m->out_dim, H, out, m->out_dim, e3);
+    launch_gemm<2>(st, cur, H, m->out_w, H, nullptr, N, m->out_dim, m->out_dim, H, out, m->out_dim, e3);
     if (m->residual && m->in_dim != m->out_dim) {
         // out += residual_proj(x): second GEMM accumulating through the residual epilogue
         GemmEpi e4 = {};
         e4.bias = m->res_b;
         e4.resid = out; e4.ldr = m->out_dim;
-        launch_gemm(st, x, m->in_dim, m->res_w, m->in_dim, nullptr, N, m->out_dim, m->out_dim, m->in_dim, out,
-                    m->out_dim, e4);
+        launch_gemm<2>(st, x, m->in_dim, m->res_w, m->in_dim, nullptr, N, m->out_dim, m->out_dim, m->in_dim, out,
+                       m->out_dim, e4);
     }
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }

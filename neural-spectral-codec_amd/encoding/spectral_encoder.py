@@ -127,7 +127,13 @@ class SpectralEncoder(nn.Module):
                                       epsilon=self.epsilon, interpolate=self.interpolate_empty)
 
     def _lut(self, dev) -> torch.Tensor:
-        return _lut_on(dev, float(self.alpha.detach()), self.n_bins, self.n_freqs, self.epsilon)
+        # alpha lives on the device; read it back only when it was modified (a .item() is a full
+        # host-device sync and would stall the launch pipeline on every call)
+        key = (self.alpha.data_ptr(), self.alpha._version)
+        if getattr(self, "_alpha_key", None) != key:
+            self._alpha_host = float(self.alpha.detach())
+            self._alpha_key = key
+        return _lut_on(dev, self._alpha_host, self.n_bins, self.n_freqs, self.epsilon)
 
     # -- reference API ------------------------------------------------------------------------
     def encode_range_image(self, range_image: torch.Tensor) -> torch.Tensor:

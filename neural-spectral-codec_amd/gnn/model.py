@@ -95,6 +95,7 @@ class SpectralGNN(nn.Module):
         else:
             self.residual_proj = None
         self._csr_cache = {}
+        self._struct_cache = None          # (key, GatModel, folded tensor)
 
     # -- plumbing ---------------------------------------------------------------------------
     def _csr(self, data, use_edge_attr: bool) -> GraphCSR:
@@ -121,6 +122,24 @@ class SpectralGNN(nn.Module):
         return t.data_ptr()
 
     def _model_struct(self) -> _lib.GatModel:
+        """NscGatModel over the live parameter storage.  Rebuilt (and the attention vectors re-folded
+        by nsc_gat_fold_weights) only when a parameter was modified or moved."""
+        params = list(self.parameters()) + list(self.buffers())
+        key = tuple((t.data_ptr(), t._version) for t in params)
+        if self._struct_cache is not None and self._struct_cache[0] == key:
+            return self._struct_cache[1]
+        m = self._build_struct()
+        L = _lib.lib()
+        dev = self.input_proj.weight.device
+        folded = torch.empty(int(L.nsc_gat_folded_floats(C.byref(m))), dtype=torch.float32, device=dev)
+        m.folded = folded.data_ptr()
+        with torch.cuda.device(dev):
+            st = L.nsc_gat_fold_weights(C.byref(m), _lib.ptr(folded), _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_gat_fold_weights")
+        self._struct_cache = (key, m, folded)
+        return m
+
+    def _build_struct(self) -> _lib.GatModel:
         m = _lib.GatModel()
         m.in_dim, m.hidden, m.out_dim = self.input_dim, self.hidden_dim, self.output_dim
         m.n_layers = self.n_layers

@@ -41,6 +41,7 @@ struct EncDev {
     float eps;
     int interp;
     int dev_skip_finish;   // development knob (NSC_TUNE_SKIP_FINISH): time the scatter phase alone
+    int dev_stagger_us;    // start-time stagger between the workgroups sharing a CU (microseconds)
 };
 
 // exp(-2 pi i j / 360) = (cos, -sin): table holds (cos, sin)
@@ -85,42 +86,43 @@ __device__ __forceinline__ void wave_sync()
 // ---------------------------------------------------------------------------------------------
 // scatter: one point into the LDS squared-range image          range_image.py:151-208
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool point_pixel(float x, float y, float z, const NscBinParams &bp,
-                                            int &pix, float &s, unsigned &flags)
-{
-    const bool fin = (fabsf(x) < INFINITY) && (fabsf(y) < INFINITY) && (fabsf(z) < INFINITY);
-    const float xs = nsc_clip_sq(x), ys = nsc_clip_sq(y), zs = nsc_clip_sq(z);
-    const float sxy = xs + ys;
-    s = sxy + zs;
-    if (!(fin && s >= bp.s_lo && s <= bp.s_hi)) return false;    // :151-155, :174-177
-    int col, row;
-    flags = 0;
-    if (!nsc_col_fast(y, x, bp.az_delta, col)) { col = nsc_col_exact(y, x); flags |= 1u; }
-    if (!nsc_row_fast(z, sxy, bp, row)) { row = nsc_row_exact(z, sxy, bp); flags |= 2u; }
-    pix = row * A + col;                                         // :202
-    return true;
-}
-
 __device__ __forceinline__ void scatter_point(float x, float y, float z, const NscBinParams &bp,
                                               unsigned *img)
 {
-    int pix; float s; unsigned fl;
-    if (point_pixel(x, y, z, bp, pix, s, fl))
+    int pix; float s;
+    if (nsc_point_pixel(x, y, z, bp, pix, s))
         atomicMin(&img[pix], __float_as_uint(s));   // ds_min_u32: s >= 0, so uint order == float order (:208)
 }
 
 template <int NT, int U>
 __device__ __forceinline__ void scatter_range(const float *__restrict__ pts, long long p0, long long p1,
-                                              int stride, int tid, const NscBinParams &bp, unsigned *img)
+                                              int stride, int tid, const NscBinParams &bp, unsigned *img,
+                                              int dev_loads_only = 0)
 {
-    const long long n = p1 - p0;
-    if (stride == 4) {
+    const int n = (int)(p1 - p0);              // a cloud holds < 2^31 points
+    if (dev_loads_only) {      // development probe: the same loads, no binning / LDS atomics
         const f32x4 *P = reinterpret_cast<const f32x4 *>(pts) + p0;
-        for (long long i = tid; i < n; i += (long long)NT * U) {
+        float s = 0.f;
+        for (int i = tid; i < n; i += NT * U) {
             f32x4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const long long j = i + (long long)u * NT;
+                const int j = i + u * NT;
+                v[u] = (j < n) ? __builtin_nontemporal_load(&P[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) s += v[u].x + v[u].y + v[u].z;
+        }
+        atomicMin(&img[tid & 63], __float_as_uint(fabsf(s)));
+        return;
+    }
+    if (stride == 4) {
+        const f32x4 *P = reinterpret_cast<const f32x4 *>(pts) + p0;
+        for (int i = tid; i < n; i += NT * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = i + u * NT;
                 if (j < n) v[u] = __builtin_nontemporal_load(&P[j]);
                 else v[u] = f32x4{NAN, 0.f, 0.f, 0.f};
             }
@@ -129,12 +131,12 @@ __device__ __forceinline__ void scatter_range(const float *__restrict__ pts, lon
         }
     } else {
         const float *P = pts + p0 * 3;
-        for (long long i = tid; i < n; i += (long long)NT * U) {
+        for (int i = tid; i < n; i += NT * U) {
             float v[U][3];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const long long j = i + (long long)u * NT;
-                if (j < n) { v[u][0] = P[j * 3]; v[u][1] = P[j * 3 + 1]; v[u][2] = P[j * 3 + 2]; }
+                const int j = i + u * NT;
+                if (j < n) { v[u][0] = P[j * 3LL]; v[u][1] = P[j * 3LL + 1]; v[u][2] = P[j * 3LL + 2]; }
                 else { v[u][0] = NAN; v[u][1] = 0.f; v[u][2] = 0.f; }
             }
 #pragma unroll
@@ -363,7 +365,9 @@ __device__ __forceinline__ void fft_row(const float *x, double2 *buf, const doub
             const double tp = zk.y + zn.y, tm = zk.y - zn.y;   // b+d, b-d
             const double xr = 0.5 * (sp + tp * w.x - sm * w.y);
             const double xi = 0.5 * (tm - sm * w.x - tp * w.y);
-            mags[k] = (float)sqrt(xr * xr + xi * xi);          // :183 (x sqrt(360) of :186 undoes 'ortho')
+            // :183 (the x sqrt(360) of :186 undoes 'ortho').  |X|^2 in float64, one float32 rounding,
+            // then a correctly rounded float32 sqrt: within 1 ULP of (float)sqrt(double)
+            mags[k] = sqrtf((float)(xr * xr + xi * xi));
         }
     }
     wave_sync();
@@ -381,9 +385,69 @@ __device__ __forceinline__ double wave_sum(double v)
 //   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
 //   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
 // ---------------------------------------------------------------------------------------------
+// Twiddles and histogram segments -> LDS, by `nthr` cooperating threads (index t).  In the fused
+// kernel one wave does this while the others already stream points, so none of its global-load
+// latency is exposed.  The LUT is monotone: bin b owns frequencies [seg[b], seg[B+b]) with
+// seg[b] = first k with lut[k] >= b and seg[B+b] = first k with lut[k] >= b+1 (equal for bins no
+// frequency maps to).  A workgroup barrier must separate this from finish_image().
+template <int NW>
+__device__ __forceinline__ void setup_tables(unsigned char *lds, const EncDev &d, const int *__restrict__ lut,
+                                             int t, int nthr)
+{
+    const LdsPlan lp = lds_plan(d.E, d.R, d.B, NW);
+    double2 *tw = reinterpret_cast<double2 *>(lds + lp.tw);
+    int *seg = reinterpret_cast<int *>(lds + lp.seg);
+    const int B = d.B;
+    for (int i = t; i < TW_N; i += nthr) tw[i] = g_tw360[i];
+    for (int b = t; b < 2 * B; b += nthr) {
+        const int key = (b < B) ? b : b - B + 1;
+        int l = 0, h = F;
+        while (l < h) { const int m = (l + h) >> 1; if (lut[m] >= key) h = m; else l = m + 1; }
+        seg[b] = l;
+    }
+}
+
+// everything after the image exists in LDS
+//   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
+//   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
+// ---------------------------------------------------------------------------------------------
+// Twiddles and histogram segments -> LDS.  Called at kernel start (before the point stream in the
+// fused kernel) so none of its global-load latency sits in the finish phase.  The LUT is monotone:
+// bin b owns frequencies [seg[b], seg[B+b]); bins no frequency maps to keep the empty segment [0,0).
+// The caller must __syncthreads() before finish_image().
+template <int NW>
+__device__ __forceinline__ void setup_tables(unsigned char *lds, const EncDev &d, const int *__restrict__ lut)
+{
+    constexpr int NT = NW * 64;
+    const int tid = threadIdx.x;
+    const LdsPlan lp = lds_plan(d.E, d.R, d.B, NW);
+    double2 *tw = reinterpret_cast<double2 *>(lds + lp.tw);
+    int *seg = reinterpret_cast<int *>(lds + lp.seg);
+    const int B = d.B;
+    for (int i = tid; i < TW_N; i += NT) tw[i] = g_tw360[i];
+    // each thread k < 181 compares lut[k] with its neighbours (3 cached loads, no LDS hand-off)
+    for (int b = tid; b < 2 * B; b += NT) {
+        // bins without frequencies: written first by the owner thread of the slot, segment starts
+        // below overwrite slots of non-empty bins only -> no race (a slot has exactly one writer:
+        // either this initialiser if the bin is empty, or the boundary thread if it is not)
+        int lo = 0;
+        const int bb = b < B ? b : b - B;
+        bool found = false;
+        // monotone LUT: binary search for the first k with lut[k] >= bb (+1 for the end)
+        int l = 0, h = F;
+        const int key = (b < B) ? bb : bb + 1;
+        while (l < h) { const int m = (l + h) >> 1; if (lut[m] >= key) h = m; else l = m + 1; }
+        lo = l; (void)found;
+        seg[b] = lo;                       // start of bin bb (b < B) or start of bin bb+1 = end of bin bb
+    }
+}
+
+// everything after the image exists in LDS
+//   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
+//   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
 template <int NW>
 __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d, int mode,
-                                             const int *__restrict__ lut, float *__restrict__ out_desc,
+                                             float *__restrict__ out_desc,
                                              float *__restrict__ out_raw, float *__restrict__ out_interp)
 {
     constexpr int NT = NW * 64;
@@ -392,66 +456,63 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
     const LdsPlan lp = lds_plan(E, R, B, NW);
     float *img = reinterpret_cast<float *>(lds + lp.img);
     float *pool = reinterpret_cast<float *>(lds + lp.pool);
-    double2 *tw = reinterpret_cast<double2 *>(lds + lp.tw);
+    const double2 *tw = reinterpret_cast<const double2 *>(lds + lp.tw);
     double2 *fftbuf = reinterpret_cast<double2 *>(lds + lp.fft) + wave * NH;
-    int *seg = reinterpret_cast<int *>(lds + lp.seg);
+    const int *seg = reinterpret_cast<const int *>(lds + lp.seg);
     double *rowsum = reinterpret_cast<double *>(lds + lp.misc);
     int *rowflag = reinterpret_cast<int *>(lds + lp.misc + MAXR * 8);
     int *rowsrc = rowflag + MAXE;
 
-    // twiddles and histogram segments (LUT is monotone: bin b owns frequencies [seg[b], seg[B+b]);
-    // bins no frequency maps to keep the empty segment [0,0))
-    for (int i = tid; i < TW_N; i += NT) tw[i] = g_tw360[i];
-    for (int b = tid; b < 2 * B; b += NT) seg[b] = 0;
-    int *lut_s = reinterpret_cast<int *>(lds + lp.fft);  // FFT scratch is free until the first FFT
-    if (wave == 0)
-        for (int k = lane; k < F; k += 64) lut_s[k] = lut[k];
-    __syncthreads();
-    if (wave == 0) {
-        for (int k = lane; k < F; k += 64) {
-            const int b = lut_s[k];
-            if (k == 0 || lut_s[k - 1] != b) seg[b] = k;
-            if (k == F - 1 || lut_s[k + 1] != b) seg[B + b] = k + 1;
-        }
-    }
-
     if (mode == 0) {
-        unsigned *raw = reinterpret_cast<unsigned *>(img);
-        for (int i = tid; i < E * A; i += NT) {
-            const unsigned v = raw[i];
-            // min over sqrtf(s_i) == sqrtf(min s_i): sqrtf is correctly rounded, hence monotone.
-            const float r = (v == NSC_EMPTY_BITS) ? 0.0f : sqrtf(__uint_as_float(v));   // :162,:214
-            img[i] = r;
-            if (out_raw) out_raw[i] = r;
-        }
-        __syncthreads();
+        // each wave converts and interpolates the rows it owns: no workgroup barrier in between
         for (int r = wave; r < E; r += NW) {
-            const int nv = interp_row(img + r * A, lane, d.interp != 0);
+            float *row = img + r * A;
+            const unsigned *raw = reinterpret_cast<const unsigned *>(row);
+            float *graw = out_raw ? out_raw + r * A : nullptr;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int c = lane + 64 * j;
+                if (c < A) {
+                    const unsigned v = raw[c];
+                    // min over sqrtf(s_i) == sqrtf(min s_i): sqrtf is correctly rounded, hence monotone
+                    const float rr = (v == NSC_EMPTY_BITS) ? 0.0f : sqrtf(__uint_as_float(v));   // :162,:214
+                    row[c] = rr;
+                    if (graw) graw[c] = rr;
+                }
+            }
+            wave_sync();
+            const int nv = interp_row(row, lane, d.interp != 0);
             if (lane == 0) rowflag[r] = (nv > 0);
         }
         __syncthreads();
         if (d.interp) {                                           // range_image.py:77-87
-            if (tid == 0) {
-                unsigned long long ne = 0ull;
-                for (int r = 0; r < E; ++r) { ne |= (unsigned long long)(rowflag[r] != 0) << r; rowsrc[r] = r; }
-                for (int r = 0; r < E; ++r) {
-                    if ((ne >> r) & 1ull) continue;
-                    for (int k = 1; k < E; ++k) {
-                        if (r - k >= 0 && ((ne >> (r - k)) & 1ull)) { rowsrc[r] = rowsrc[r - k]; ne |= 1ull << r; break; }
-                        if (r + k < E && ((ne >> (r + k)) & 1ull)) { rowsrc[r] = r + k; ne |= 1ull << r; break; }
+            unsigned long long ne = 0ull;
+            for (int r = 0; r < E; ++r) ne |= (unsigned long long)(rowflag[r] != 0) << r;
+            const unsigned long long all = (E == 64) ? ~0ull : ((1ull << E) - 1ull);
+            if (ne != all && ne != 0ull) {                        // some (not all) rows are empty: rare
+                if (tid == 0) {
+                    unsigned long long m = ne;
+                    for (int r = 0; r < E; ++r) rowsrc[r] = r;
+                    for (int r = 0; r < E; ++r) {
+                        if ((m >> r) & 1ull) continue;
+                        for (int k = 1; k < E; ++k) {
+                            if (r - k >= 0 && ((m >> (r - k)) & 1ull)) { rowsrc[r] = rowsrc[r - k]; m |= 1ull << r; break; }
+                            if (r + k < E && ((m >> (r + k)) & 1ull)) { rowsrc[r] = r + k; m |= 1ull << r; break; }
+                        }
                     }
                 }
+                __syncthreads();
+                for (int r = wave; r < E; r += NW) {
+                    const int sr = rowsrc[r];                     // always an original (never copied) row
+                    if (sr != r)
+                        for (int c = lane; c < A; c += 64) img[r * A + c] = img[sr * A + c];
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            for (int r = wave; r < E; r += NW) {
-                const int s = rowsrc[r];                          // always an original (never copied) row
-                if (s != r)
-                    for (int c = lane; c < A; c += 64) img[r * A + c] = img[s * A + c];
-            }
-            __syncthreads();
         }
         if (out_interp)
-            for (int i = tid; i < E * A; i += NT) out_interp[i] = img[i];
+            for (int r = wave; r < E; r += NW)                    // rows this wave owns (or just copied)
+                for (int c = lane; c < A; c += 64) out_interp[r * A + c] = img[r * A + c];
     }
 
     float *rows = img;
@@ -460,13 +521,13 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
             const int pr = i / A, c = i - pr * A;
             const int r0 = (pr * E) / R;
             const int r1 = ((pr + 1) * E + R - 1) / R;
-            float s = 0.0f;
-            for (int r = r0; r < r1; ++r) s += img[r * A + c];
-            pool[i] = s / (float)(r1 - r0);
+            float sacc = 0.0f;
+            for (int r = r0; r < r1; ++r) sacc += img[r * A + c];
+            pool[i] = sacc / (float)(r1 - r0);
         }
         rows = pool;
+        __syncthreads();
     }
-    __syncthreads();                                              // also orders lut_s reads before FFT writes
     if (d.dev_skip_finish & 16) return;
 
     for (int r = wave; r < R; r += NW) {
@@ -479,7 +540,13 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
         for (int b = lane; b < B; b += 64) {
             float h = 0.0f;
             const int k1 = seg[B + b];
-            for (int k = seg[b]; k < k1; ++k) h += mags[k];      // scatter_add_, ascending k (:152-155)
+            for (int k = seg[b]; k < k1; k += 8) {               // scatter_add_, ascending k (:152-155)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (k + u < k1) ? mags[k + u] : 0.0f;   // loads issued together
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h += v[u];            // h + 0.0f == h: order and rounding unchanged
+            }
             hist[b] = h;
             part += (double)h;
         }
@@ -521,15 +588,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void encode_fused_kernel(
     unsigned *img = reinterpret_cast<unsigned *>(lds);
     const int npix = d.E * A;
     for (int i = tid; i < npix; i += NT) img[i] = NSC_EMPTY_BITS;  // :205 full(inf)
+    if (d.dev_stagger_us > 0) {
+        // Desynchronise the workgroups that share a CU (observed placement: consecutive groups of
+        // 256 blocks fill one slot per CU): a later slot starts its point stream a little later, so
+        // its finish phase overlaps the other slots' streaming instead of idling HBM.  Speed only:
+        // any placement gives the same results.
+        const int slot = blockIdx.x >> 8;
+        if (slot > 0 && slot < 8) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+            const unsigned long long wait = (unsigned long long)d.dev_stagger_us * 100ull * slot;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     __syncthreads();
-    scatter_range<NT, U>(pts, off[c], off[c + 1], stride, tid, d.bp, img);
+    if (tid >= NT - 64) setup_tables<NW>(lds, d, lut, tid - (NT - 64), 64);   // last wave; joins the stream late
+    scatter_range<NT, U>(pts, off[c], off[c + 1], stride, tid, d.bp, img, d.dev_skip_finish & 32);
     __syncthreads();
     if (d.dev_skip_finish & 1) {
         if (tid == 0) out_desc[(long long)c * d.R * d.B] = __uint_as_float(img[0]);
         return;
     }
     const long long D = (long long)d.R * d.B;
-    finish_image<NW>(lds, d, 0, lut, out_desc + c * D,
+    finish_image<NW>(lds, d, 0, out_desc + c * D,
                      out_raw ? out_raw + (long long)c * npix : nullptr,
                      out_interp ? out_interp + (long long)c * npix : nullptr);
 }
@@ -571,6 +651,7 @@ __global__ __launch_bounds__(NW * 64) void finish_kernel(
     constexpr int NT = NW * 64;
     const int c = blockIdx.x, tid = threadIdx.x;
     const int npix = d.E * A;
+    setup_tables<NW>(lds, d, lut, tid, NT);
     {
         // 16-byte loads, all issued before the LDS stores (rows are 1 440 B, images 16-B aligned)
         const f32x4 *g = src_u32 ? reinterpret_cast<const f32x4 *>(src_u32 + (long long)c * npix)
@@ -593,7 +674,7 @@ __global__ __launch_bounds__(NW * 64) void finish_kernel(
     }
     __syncthreads();
     const long long D = (long long)d.R * d.B;
-    finish_image<NW>(lds, d, src_u32 ? 0 : 1, lut, out_desc + c * D,
+    finish_image<NW>(lds, d, src_u32 ? 0 : 1, out_desc + c * D,
                      out_raw ? out_raw + (long long)c * npix : nullptr,
                      out_interp ? out_interp + (long long)c * npix : nullptr);
 }
@@ -605,18 +686,18 @@ __global__ __launch_bounds__(256) void point_bins_kernel(
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const float x = pts[i * stride], y = pts[i * stride + 1], z = pts[i * stride + 2];
-        int pix; float s; unsigned fl = 0;
-        const bool ok = point_pixel(x, y, z, bp, pix, s, fl);
-        out_idx[i] = ok ? pix : -1;
-        if (out_flags) out_flags[i] = ok ? (unsigned char)fl : (unsigned char)0;
+        int pix; float s;
+        const int fl = nsc_point_pixel(x, y, z, bp, pix, s);
+        out_idx[i] = fl ? pix : -1;
+        if (out_flags) out_flags[i] = (unsigned char)(fl >> 1);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side of the ABI
 // ---------------------------------------------------------------------------------------------
-constexpr int FUSED_NW = 8;          // 512 threads per workgroup
-constexpr int FUSED_U = 4;           // float4 loads in flight per thread
+constexpr int FUSED_NW = 8;          // split / finish kernels: 512 threads per workgroup
+constexpr int FUSED_U = 4;           // float4 loads in flight per thread (split scatter)
 constexpr int SPLIT_MIN_PTS = 16384; // a part must amortise its 5 760-pixel LDS init + flush
 constexpr int SPLIT_TARGET_WGS = 512;
 
@@ -648,6 +729,7 @@ EncDev make_dev(const NscEncParams *p, int rows_in)
     d.eps = p->epsilon;
     d.interp = p->interpolate;
     d.dev_skip_finish = tune_env("NSC_TUNE_SKIP_FINISH", 0);
+    d.dev_stagger_us = tune_env("NSC_TUNE_STAGGER_US", 0);
     return d;
 }
 
@@ -743,13 +825,11 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
     }
         switch (variant) {
         case 1: NSC_LAUNCH_FUSED(4, 4, 4) break;
-        case 2: NSC_LAUNCH_FUSED(4, 8, 4) break;
-        case 3: NSC_LAUNCH_FUSED(8, 8, 4) break;
-        case 4: NSC_LAUNCH_FUSED(16, 4, 2) break;
-        case 5: NSC_LAUNCH_FUSED(4, 16, 4) break;
-        case 6: NSC_LAUNCH_FUSED(8, 4, 4) break;
-        case 7: NSC_LAUNCH_FUSED(4, 2, 4) break;
-        default: NSC_LAUNCH_FUSED(8, 4, 4) break;
+        case 2: NSC_LAUNCH_FUSED(8, 8, 4) break;
+        case 3: NSC_LAUNCH_FUSED(8, 4, 4) break;
+        // default: 4 waves x 8 float4 loads in flight per lane, 39.4 KB LDS -> 4 workgroups per CU:
+        // a 1 024-cloud batch is exactly one resident round (interleaved A/B, profiles/r01_*).
+        default: NSC_LAUNCH_FUSED(4, 8, 4) break;
         }
     } else {
         const size_t need = (size_t)n_clouds * d.E * A * sizeof(unsigned);

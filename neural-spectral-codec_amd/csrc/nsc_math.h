@@ -28,8 +28,12 @@ struct NscBinParams {
     float el_scale;            // E / espan, float32, for the fast estimate
     float az_delta, el_delta;  // acceptance margins of the fast estimate, in bin units
     float s_lo, s_hi;          // range filter expressed on the squared range (see host code)
+    float el_u_scale, el_u_bias; // narrow-FOV row estimate: u = atan(t) * scale + bias
     int E;                     // projector rows
     int elev_f64;              // row math in float64 (numpy >= 2) or float32 (numpy 1.24)
+    int narrow_fov;            // both FOV edges within |tan| < 0.58: cheap row estimate is valid
+    int simple_valid;          // s_hi < 1e10: the 1e10 clip and the isfinite tests are implied by the
+                               // squared-range window (inf/NaN coordinates give s = inf/NaN -> dropped)
 };
 
 // ---- exact chain ----------------------------------------------------------------------------
@@ -101,19 +105,42 @@ NSC_HD float nsc_sqrt_approx(float x)
 #endif
 }
 
-// atan(t) for t in [0,1]: t * P(t^2), degree-8 minimax (5.8e-9 rad exact, < 1e-7 rad in float32)
+NSC_HD float nsc_rsq_approx(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);    // v_rsq_f32, 1 ULP
+#elif defined(NSC_TEST_APPROX_BIAS)
+    return nextafterf(1.0f / sqrtf(x), NSC_TEST_APPROX_BIAS > 0 ? INFINITY : 0.0f);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+
+// atan(t) for t in [0,1]: t * P(t^2), degree-7 minimax (3.7e-8 rad exact, 1.4e-7 rad in float32)
 NSC_HD float nsc_atan01(float t)
 {
     const float w = t * t;
-    float p = 2.4567242624e-03f;
-    p = __builtin_fmaf(p, w, -1.4401357072e-02f);
-    p = __builtin_fmaf(p, w, 3.9781223114e-02f);
-    p = __builtin_fmaf(p, w, -7.2348574340e-02f);
-    p = __builtin_fmaf(p, w, 1.0498946179e-01f);
-    p = __builtin_fmaf(p, w, -1.4161229249e-01f);
-    p = __builtin_fmaf(p, w, 1.9985906780e-01f);
-    p = __builtin_fmaf(p, w, -3.3332597030e-01f);
-    p = __builtin_fmaf(p, w, 9.9999988638e-01f);
+    float p = -4.0545659302e-03f;
+    p = __builtin_fmaf(p, w, 2.1862953564e-02f);
+    p = __builtin_fmaf(p, w, -5.5912321150e-02f);
+    p = __builtin_fmaf(p, w, 9.6421969742e-02f);
+    p = __builtin_fmaf(p, w, -1.3908629443e-01f);
+    p = __builtin_fmaf(p, w, 1.9946565639e-01f);
+    p = __builtin_fmaf(p, w, -3.3329860785e-01f);
+    p = __builtin_fmaf(p, w, 9.9999933558e-01f);
+    return p * t;
+}
+
+// atan(t) for |t| <= 0.62: degree-5 minimax in t^2 (1.3e-8 rad exact, 8e-8 rad in float32)
+NSC_HD float nsc_atan_small(float t)
+{
+    const float w = t * t;
+    float p = -3.6013321370e-02f;
+    p = __builtin_fmaf(p, w, 8.9950942561e-02f);
+    p = __builtin_fmaf(p, w, -1.3851101441e-01f);
+    p = __builtin_fmaf(p, w, 1.9954741257e-01f);
+    p = __builtin_fmaf(p, w, -3.3331274679e-01f);
+    p = __builtin_fmaf(p, w, 9.9999973037e-01f);
     return p * t;
 }
 
@@ -152,6 +179,47 @@ NSC_HD bool nsc_row_fast(float z, float sxy, const NscBinParams &bp, int &row)
     row = r;
     const float d = bp.el_delta;
     return ((f > d) && (f < 1.0f - d)) || (u < -d) || (u > (float)bp.E + d);
+}
+
+// Row estimate for sensors whose FOV edges lie within |tan(elevation)| < 0.58 (about +-30 deg, every
+// FOV the reference configures): t = z / rxy straight from v_rsq_f32, no octant logic.  |t| is
+// clamped to 0.62, beyond which the row is clamped to 0 / E-1 with a margin of > 0.4 rows.
+NSC_HD bool nsc_row_fast_narrow(float z, float sxy, const NscBinParams &bp, int &row)
+{
+    float t = z * nsc_rsq_approx(sxy);
+    t = fminf(fmaxf(t, -0.62f), 0.62f);       // z = 0 and sxy = 0 gives NaN: ruled uncertain below
+    const float u = __builtin_fmaf(nsc_atan_small(t), bp.el_u_scale, bp.el_u_bias);
+    const float fi = floorf(u);
+    const float f = u - fi;
+    row = (int)fminf(fmaxf(fi, 0.0f), (float)(bp.E - 1));
+    const float d = bp.el_delta;
+    return (((f > d) && (f < 1.0f - d)) || (u < -d) || (u > (float)bp.E + d)) && (sxy > 0.0f);
+}
+
+// One point -> (pixel, squared range).  Returns 0 if the point is dropped, else 1 | 2*(exact path
+// decided the column) | 4*(exact path decided the row).            range_image.py:151-202
+NSC_HD int nsc_point_pixel(float x, float y, float z, const NscBinParams &bp, int &pix, float &s)
+{
+    float sxy;
+    if (bp.simple_valid) {
+        sxy = x * x + y * y;
+        s = sxy + z * z;
+        if (!(s >= bp.s_lo && s <= bp.s_hi)) return 0;                // :151-155, :174-177
+    } else {
+        const bool fin = (fabsf(x) < INFINITY) && (fabsf(y) < INFINITY) && (fabsf(z) < INFINITY);
+        sxy = nsc_clip_sq(x) + nsc_clip_sq(y);
+        s = sxy + nsc_clip_sq(z);
+        if (!(fin && s >= bp.s_lo && s <= bp.s_hi)) return 0;
+    }
+    int col, row, flags = 1;
+    const bool cok = nsc_col_fast(y, x, bp.az_delta, col);
+    const bool rok = bp.narrow_fov ? nsc_row_fast_narrow(z, sxy, bp, row) : nsc_row_fast(z, sxy, bp, row);
+    if (__builtin_expect(!(cok && rok), 0)) {
+        if (!cok) { col = nsc_col_exact(y, x); flags |= 2; }
+        if (!rok) { row = nsc_row_exact(z, sxy, bp); flags |= 4; }
+    }
+    pix = row * NSC_A + col;                                          // :202
+    return flags;
 }
 
 // ---- host-side setup (plain C++, also used by the CPU margin tests) ---------------------------
@@ -226,5 +294,9 @@ inline NscBinParams nsc_make_bin_params(int E, double emin, double emax, float r
     bp.s_lo = nsc_first_true([&](float s) { return sqrtf(s) >= rmin; });
     const float above = nsc_first_true([&](float s) { return sqrtf(s) > rmax; });
     bp.s_hi = nextafterf(above, 0.0f);
+    bp.el_u_scale = bp.el_scale;
+    bp.el_u_bias = (float)(-emin * ((double)E / bp.espan));
+    bp.narrow_fov = (fabs(tan(emin)) < 0.58 && fabs(tan(emax)) < 0.58 && fabs(emin) < 1.0 && fabs(emax) < 1.0);
+    bp.simple_valid = (bp.s_hi < 1e10f);
     return bp;
 }

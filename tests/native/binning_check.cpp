@@ -46,15 +46,25 @@ int main(int argc, char **argv)
             z = (float)((u01() * 2 - 1) * 30);
             if ((next() % 16) == 0) y = 0.0f;
             if ((next() % 16) == 0) x = -0.0f;
+            if ((next() % 64) == 0) x = INFINITY;
+            if ((next() % 64) == 0) y = NAN;
+            if ((next() % 64) == 0) z = -INFINITY;
+            if ((next() % 64) == 0) x = 3e25f;
         }
+        // reference decision, exact chain with the clip and isfinite tests spelled out
         const float xs = nsc_clip_sq(x), ys = nsc_clip_sq(y), zs = nsc_clip_sq(z);
         const float sxy = xs + ys, ss = sxy + zs;
-        if (!(ss >= bp.s_lo && ss <= bp.s_hi)) continue;
-        int cf, rf;
-        bool cok = nsc_col_fast(y, x, bp.az_delta, cf);
-        bool rok = nsc_row_fast(z, sxy, bp, rf);
-        if (!cok) ++azu; else if (cf != nsc_col_exact(y, x)) ++azw;
-        if (!rok) ++elu; else if (rf != nsc_row_exact(z, sxy, bp)) ++elw;
+        const bool keep = isfinite(x) && isfinite(y) && isfinite(z) && ss >= bp.s_lo && ss <= bp.s_hi;
+        int pix; float sv;
+        const int fl = nsc_point_pixel(x, y, z, bp, pix, sv);      // what the kernel runs
+        if ((fl != 0) != keep) { ++azw; ++elw; continue; }
+        if (!keep) continue;
+        const int ec = nsc_col_exact(y, x), er = nsc_row_exact(z, sxy, bp);
+        if (fl & 2) ++azu;
+        if (fl & 4) ++elu;
+        if (pix % NSC_A != ec) ++azw;
+        if (pix / NSC_A != er) ++elw;
+        if (sv != ss) ++azw;
     }
     printf("%ld %ld %ld %ld %ld %.9g %.9g %.9g\n", n, azu, elu, azw, elw, (double)nsc_az_edge_slack(),
            (double)bp.s_lo, (double)bp.s_hi);

@@ -98,6 +98,13 @@ class SpectralGNN(nn.Module):
         self._struct_cache = None          # (key, GatModel, folded tensor)
 
     # -- plumbing ---------------------------------------------------------------------------
+    def __getstate__(self):
+        # device-pointer caches are rebuilt on demand; keep them out of deepcopy / pickle / torch.save
+        state = self.__dict__.copy()
+        state["_csr_cache"] = {}
+        state["_struct_cache"] = None
+        return state
+
     def _csr(self, data, use_edge_attr: bool) -> GraphCSR:
         ei = data.edge_index
         ea = getattr(data, "edge_attr", None) if use_edge_attr else None

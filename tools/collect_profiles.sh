@@ -1,0 +1,10 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): bench line + rocprofv3 kernel stats of the same command.
+# Outputs land in gpurun_out/; copy the summaries you want judged into profiles/.
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_prof.log 2>&1
+tail -c 3000 $R/gpurun_out/${TAG}_bench.json

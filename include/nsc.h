@@ -140,6 +140,10 @@ typedef struct NscGraph {
     const int32_t *src;           /* (nnz) source node of each entry, entries of a target in edge order */
     const int32_t *eid;           /* (nnz) index into the caller's edge list, -1 for the self loop */
     const float   *loop_attr;     /* (n_nodes, edge_dim) or NULL */
+    /* transposed view (entries grouped by SOURCE), needed by nsc_gat_backward only; NULL otherwise */
+    const int32_t *t_ptr;         /* (n_nodes+1) */
+    const int32_t *t_entry;       /* (nnz) entry indices into src/eid, ascending per source */
+    const int32_t *tgt;           /* (nnz) target node of each entry */
 } NscGraph;
 
 size_t nsc_graph_workspace_bytes(int32_t n_nodes, int64_t n_edges);
@@ -167,6 +171,50 @@ size_t nsc_gat_workspace_bytes(const NscGatModel *m, int32_t n_nodes);
  *   alpha_out  nullable (n_layers, nnz) attention coefficients (forward_with_attention) */
 int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                     float *out, float *alpha_out, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training step of the GNN (BASELINE configs[4]): model.train(); emb = model(graph);
+ * loss = TripletLoss(emb[a], emb[p], emb[n]); loss.backward()
+ * (reference src/gnn/trainer.py:205-213, TripletLoss :44-68; model.py:96-153 in train mode:
+ * BatchNorm batch statistics, feature dropout :137, GATConv attention dropout).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct NscGatTrainCfg {
+    float    dropout_p;            /* model.py:38; 0 for parity runs (the reference never seeds its RNG) */
+    float    bn_momentum;          /* 0.1 (nn.BatchNorm1d default) */
+    uint64_t seed;                 /* counter-based dropout masks: same seed in forward and backward */
+    int32_t  update_running_stats; /* 1: running_mean / running_var of the model are updated IN PLACE */
+} NscGatTrainCfg;
+
+typedef struct NscGatGradLayer {   /* device buffers shaped like the NscGatLayer parameters; overwritten */
+    float *lin_w, *att_src, *att_dst, *lin_edge_w, *att_edge, *bias, *bn_w, *bn_b;
+} NscGatGradLayer;
+
+typedef struct NscGatGrads {
+    float *in_w, *in_b, *in_bn_w, *in_bn_b, *out_w, *out_b;
+    float *x;                      /* nullable: gradient w.r.t. the input features (n_nodes, in_dim) */
+    NscGatGradLayer layers[NSC_GAT_MAX_LAYERS];
+} NscGatGrads;
+
+size_t nsc_graph_transpose_workspace_bytes(int32_t n_nodes);
+int    nsc_graph_transpose(const NscGraph *g, int32_t *t_ptr, int32_t *t_entry, int32_t *tgt, void *ws,
+                           size_t ws_bytes, void *stream);
+
+/* The workspace holds the activations the forward saves for the backward: pass the SAME buffer (and
+ * cfg) to nsc_gat_backward.  Requires in_dim == out_dim when residual is set (the reference's shape). */
+size_t nsc_gat_train_workspace_bytes(const NscGatModel *m, const NscGraph *g);
+int    nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
+                             const NscGatTrainCfg *cfg, float *out, void *ws, size_t ws_bytes, void *stream);
+int    nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
+                        const NscGatTrainCfg *cfg, const float *grad_out, const NscGatGrads *grads, void *ws,
+                        size_t ws_bytes, void *stream);
+
+/* TripletLoss forward (+ backward when grad_emb != NULL): loss = scale * mean_t relu(|a-p|^2 - |a-n|^2 + margin);
+ * grad_emb (n_nodes, dim) is zeroed and receives d loss / d emb. */
+size_t nsc_triplet_workspace_bytes(int32_t n_triplets);
+int    nsc_triplet_loss(const float *emb, const int64_t *anchors, const int64_t *positives,
+                        const int64_t *negatives, int32_t n_triplets, int32_t n_nodes, int32_t dim,
+                        float margin, float scale, float *loss, float *grad_emb, void *ws, size_t ws_bytes,
+                        void *stream);
 
 #ifdef __cplusplus
 }

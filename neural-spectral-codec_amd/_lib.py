@@ -51,7 +51,26 @@ class GatModel(C.Structure):
 class Graph(C.Structure):
     """struct NscGraph"""
     _fields_ = [("n_nodes", C.c_int32), ("nnz", C.c_int32), ("row_ptr", C.c_void_p),
-                ("src", C.c_void_p), ("eid", C.c_void_p), ("loop_attr", C.c_void_p)]
+                ("src", C.c_void_p), ("eid", C.c_void_p), ("loop_attr", C.c_void_p),
+                ("t_ptr", C.c_void_p), ("t_entry", C.c_void_p), ("tgt", C.c_void_p)]
+
+
+class GatTrainCfg(C.Structure):
+    """struct NscGatTrainCfg"""
+    _fields_ = [("dropout_p", C.c_float), ("bn_momentum", C.c_float), ("seed", C.c_uint64),
+                ("update_running_stats", C.c_int32)]
+
+
+class GatGradLayer(C.Structure):
+    """struct NscGatGradLayer"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "lin_w", "att_src", "att_dst", "lin_edge_w", "att_edge", "bias", "bn_w", "bn_b")]
+
+
+class GatGrads(C.Structure):
+    """struct NscGatGrads"""
+    _fields_ = [(n, C.c_void_p) for n in ("in_w", "in_b", "in_bn_w", "in_bn_b", "out_w", "out_b", "x")] + [
+        ("layers", GatGradLayer * GAT_MAX_LAYERS)]
 
 
 _lib = None
@@ -73,6 +92,16 @@ SYMBOLS = {
     "nsc_gat_fold_weights": (C.c_int, [C.POINTER(GatModel), _vp, _vp]),
     "nsc_gat_workspace_bytes": (_sz, [C.POINTER(GatModel), _i32]),
     "nsc_gat_forward": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_graph_transpose_workspace_bytes": (_sz, [_i32]),
+    "nsc_graph_transpose": (C.c_int, [C.POINTER(Graph), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_gat_train_workspace_bytes": (_sz, [C.POINTER(GatModel), C.POINTER(Graph)]),
+    "nsc_gat_forward_train": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, C.POINTER(GatTrainCfg),
+                                        _vp, _vp, _sz, _vp]),
+    "nsc_gat_backward": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, C.POINTER(GatTrainCfg), _vp,
+                                   C.POINTER(GatGrads), _vp, _sz, _vp]),
+    "nsc_triplet_workspace_bytes": (_sz, [_i32]),
+    "nsc_triplet_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, C.c_float, _vp, _vp, _vp,
+                                   _sz, _vp]),
 }
 
 

@@ -1,0 +1,920 @@
+// nsc_gat_train.hip -- gfx950 kernels + C ABI for the training step of the GNN enhancer
+// (BASELINE.json configs[4]: triplet loss + GAT backward).
+//
+// Path (reference file:line):
+//   SpectralGNN.forward in train() mode          src/gnn/model.py:96-153 (BatchNorm batch statistics
+//                                                :117,:132, feature dropout :137, GATConv attention dropout)
+//   TripletLoss.forward                          src/gnn/trainer.py:44-68
+//   loss.backward() through the full graph       src/gnn/trainer.py:205-213
+//
+// Structure: the forward saves z (pre-BatchNorm activations), the per-layer transformed features g,
+// attention logits parts and softmax weights in a caller workspace; the backward walks the layers in
+// reverse with (a) column reductions for BatchNorm / bias / attention-vector gradients (two-pass,
+// float64 partials, deterministic), (b) a per-target kernel for the softmax / leaky-ReLU backward,
+// (c) a per-source kernel (transposed CSR, no atomics) for the feature gradient, (d) f32-MFMA GEMMs in
+// NT / NN / TN form with split-K slabs for the weight gradients (deterministic reduce).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "../../include/nsc.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// ---------------------------------------------------------------------------------------------
+// counter-based dropout mask: keep iff u01(hash(seed, stream, idx)) >= p
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline unsigned hash3(unsigned long long seed, unsigned stream, unsigned long long idx)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((unsigned long long)stream << 48);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;       // splitmix64 finaliser
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (unsigned)(z >> 40);                        // 24 random bits
+}
+__device__ __forceinline__ float keep_scale(float p, unsigned long long seed, unsigned stream,
+                                            unsigned long long idx)
+{
+    if (p <= 0.0f) return 1.0f;
+    const float u = (float)hash3(seed, stream, idx) * (1.0f / 16777216.0f);
+    return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// general f32-MFMA GEMM:  C[M,N] = sum_k A(m,k) * B(n,k)
+//   AKM = false: A(m,k) = A[m*lda + k] (k contiguous);  AKM = true: A(m,k) = A[k*lda + m] (m contiguous)
+//   same for B.  blockIdx.z = split-K slice; slices write their own (M,N) slab.
+// ---------------------------------------------------------------------------------------------
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_gen_kernel(const float *__restrict__ A, int lda,
+                                                       const float *__restrict__ B, int ldb, int M, int N,
+                                                       int K, int kchunk, float *__restrict__ C, int ldc,
+                                                       long long slab, const float *__restrict__ bias,
+                                                       int accumulate)
+{
+    constexpr int BM = 32, BN = 64, BK = 64, LD = BK + 4;
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k0 = blockIdx.z * kchunk, k1 = min(K, k0 + kchunk);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2] = {zero, zero};
+
+    for (int kb = k0; kb < k1; kb += BK) {
+        // ---- stage A tile (BM x BK) ----
+#pragma unroll
+        for (int i = 0; i < BM * BK / 4 / 256; ++i) {
+            const int f = tid + 256 * i;
+            if (!AKM) {
+                const int row = f >> 4, c4 = f & 15, gm = m0 + row, gk = kb + 4 * c4;
+                f32x4 v = zero;
+                if (gm < M && gk + 3 < k1) v = *reinterpret_cast<const f32x4 *>(A + (long long)gm * lda + gk);
+                else if (gm < M)
+                    for (int j = 0; j < 4; ++j) if (gk + j < k1) v[j] = A[(long long)gm * lda + gk + j];
+                *reinterpret_cast<f32x4 *>(&As[row * LD + 4 * c4]) = v;
+            } else {
+                const int kl = f / (BM / 4), m4 = f % (BM / 4), gk = kb + kl, gm = m0 + 4 * m4;
+                f32x4 v = zero;
+                if (gk < k1 && gm + 3 < M) v = *reinterpret_cast<const f32x4 *>(A + (long long)gk * lda + gm);
+                else if (gk < k1)
+                    for (int j = 0; j < 4; ++j) if (gm + j < M) v[j] = A[(long long)gk * lda + gm + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(4 * m4 + j) * LD + kl] = v[j];
+            }
+        }
+        // ---- stage B tile (BN x BK) ----
+#pragma unroll
+        for (int i = 0; i < BN * BK / 4 / 256; ++i) {
+            const int f = tid + 256 * i;
+            if (!BKM) {
+                const int row = f >> 4, c4 = f & 15, gn = n0 + row, gk = kb + 4 * c4;
+                f32x4 v = zero;
+                if (gn < N && gk + 3 < k1) v = *reinterpret_cast<const f32x4 *>(B + (long long)gn * ldb + gk);
+                else if (gn < N)
+                    for (int j = 0; j < 4; ++j) if (gk + j < k1) v[j] = B[(long long)gn * ldb + gk + j];
+                *reinterpret_cast<f32x4 *>(&Bs[row * LD + 4 * c4]) = v;
+            } else {
+                const int kl = f / (BN / 4), n4 = f % (BN / 4), gk = kb + kl, gn = n0 + 4 * n4;
+                f32x4 v = zero;
+                if (gk < k1 && gn + 3 < N) v = *reinterpret_cast<const f32x4 *>(B + (long long)gk * ldb + gn);
+                else if (gk < k1)
+                    for (int j = 0; j < 4; ++j) if (gn + j < N) v[j] = B[(long long)gk * ldb + gn + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * n4 + j) * LD + kl] = v[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < BK / 16; ++d) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(&Bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&As[r * LD + 16 * d + 4 * q]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&As[(16 + r) * LD + 16 * d + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], bv[t], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], bv[t], acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wave * 16 + r;
+    if (col >= N) return;
+    float *Cz = C + (long long)blockIdx.z * slab;
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = m0 + 16 * h + 4 * q + reg;
+            if (row >= M) continue;
+            float v = acc[h][reg] + bv;
+            float *dst = Cz + (long long)row * ldc + col;
+            if (accumulate) v += *dst;
+            *dst = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ part, int S, long long MN,
+                                                          float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.0f;
+    for (int z = 0; z < S; ++z) s += part[(long long)z * MN + i];     // fixed order: deterministic
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reductions over the N rows of an (N, C) matrix, float64 partials, two passes:
+//   out_a[c] = sum_n P[n][c] * (w ? w[n] : 1)
+//   out_b[c] = sum_n P[n][c] * Q'[n][c],  Q' = Q or (Q - qm[c]) * qs[c]        (Q nullable)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__restrict__ P,
+                                                                const float *__restrict__ w,
+                                                                const float *__restrict__ Q,
+                                                                const float *__restrict__ qm,
+                                                                const float *__restrict__ qs, int N, int C,
+                                                                int rows_per_block, double *__restrict__ part)
+{
+    __shared__ double sa[256], sb[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const float m = qm ? qm[c] : 0.0f, s = qs ? qs[c] : 1.0f;
+        for (int n = n0 + ry; n < n1; n += 4) {
+            const float p = P[(long long)n * C + c];
+            a += (double)(w ? p * w[n] : p);
+            if (Q) {
+                float qv = Q[(long long)n * C + c];
+                if (qm) qv = (qv - m) * s;
+                b += (double)p * (double)qv;
+            }
+        }
+    }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        a = sa[cx] + sa[64 + cx] + sa[128 + cx] + sa[192 + cx];
+        b = sb[cx] + sb[64 + cx] + sb[128 + cx] + sb[192 + cx];
+        part[((long long)blockIdx.y * C + c) * 2] = a;
+        part[((long long)blockIdx.y * C + c) * 2 + 1] = b;
+    }
+}
+
+// mode 0: out_a = A, out_b = B (plain sums, nullable outputs)
+// mode 1: BatchNorm statistics of P (Q = P): mean = A/N, var = B/N - mean^2 -> out_a = mean,
+//         out_b = 1/sqrt(var+eps); optional running-stat update (momentum, unbiased variance)
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C,
+                                                              int mode, int N, float eps, float momentum,
+                                                              float *__restrict__ out_a, float *__restrict__ out_b,
+                                                              float *__restrict__ run_mean, float *__restrict__ run_var)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < R; ++r) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
+    if (mode == 0) {
+        if (out_a) out_a[c] = (float)a;
+        if (out_b) out_b[c] = (float)b;
+    } else {
+        const double mean = a / N;
+        double var = b / N - mean * mean;
+        if (var < 0.0) var = 0.0;
+        out_a[c] = (float)mean;
+        out_b[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {                                   // nn.BatchNorm1d: momentum 0.1, unbiased running_var
+            const double unb = N > 1 ? var * N / (N - 1) : var;
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm(train) apply + ReLU + dropout + residual:  h = drop(relu(gamma*xhat + beta)) + resid
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ z, const float *__restrict__ mean,
+                                                     const float *__restrict__ invstd,
+                                                     const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, int relu, float p,
+                                                     unsigned long long seed, unsigned stream,
+                                                     const float *__restrict__ resid, long long total, int C,
+                                                     float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    if (relu) v = fmaxf(v, 0.0f);
+    v *= keep_scale(p, seed, stream, (unsigned long long)i);
+    if (resid) v += resid[i];
+    out[i] = v;
+}
+
+// dV = dH * dropmask * relu'(v),  v recomputed from z and the batch statistics
+__global__ __launch_bounds__(256) void bn_act_bwd_dv_kernel(const float *__restrict__ dh,
+                                                            const float *__restrict__ z,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int relu, float p,
+                                                            unsigned long long seed, unsigned stream,
+                                                            long long total, int C, float *__restrict__ dv)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float g = dh[i] * keep_scale(p, seed, stream, (unsigned long long)i);
+    if (relu) {
+        const float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (!(v > 0.0f)) g = 0.0f;
+    }
+    dv[i] = g;
+}
+
+// dZ = gamma*invstd*(dV - s1/N - xhat*s2/N)   (s1 = sum dV, s2 = sum dV*xhat per column)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ dv,
+                                                           const float *__restrict__ z,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ s1,
+                                                           const float *__restrict__ s2, long long total, int C,
+                                                           int N, float *__restrict__ dz)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const float xhat = (z[i] - mean[c]) * invstd[c];
+    const float invn = 1.0f / (float)N;
+    dz[i] = gamma[c] * invstd[c] * (dv[i] - s1[c] * invn - xhat * s2[c] * invn);
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b,
+                                                          long long total)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) a[i] += b[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention (training): logits from the true definition a_src = <g, att_src>, a_dst = <g, att_dst>
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sumf(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_maxf(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// a_src[i] = <g_i, att_src>, a_dst[i] = <g_i, att_dst>; one wave per node
+__global__ __launch_bounds__(256) void att_dots_kernel(const float *__restrict__ G, const float *__restrict__ att_s,
+                                                       const float *__restrict__ att_d, int N, int H,
+                                                       float *__restrict__ a_src, float *__restrict__ a_dst)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    float s = 0.f, d = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float g = G[(long long)i * H + c];
+        s = __builtin_fmaf(g, att_s[c], s);
+        d = __builtin_fmaf(g, att_d[c], d);
+    }
+    s = wave_sumf(s); d = wave_sumf(d);
+    if (lane == 0) { a_src[i] = s; a_dst[i] = d; }
+}
+
+struct TrainAgg {
+    const int *row_ptr, *src, *eid;
+    const float *loop_attr, *edge_attr, *v;   // v = W_edge^T att_edge (edge_dim), nullable
+    const float *a_src, *a_dst, *G, *bias;
+    float *alpha;                             // (nnz) softmax weights BEFORE dropout (saved)
+    float *y;                                 // (N,H) aggregate + bias (pre-BatchNorm)
+    float slope, p;
+    unsigned long long seed;
+    unsigned stream;
+    int N, H, edge_dim;
+};
+
+__device__ __forceinline__ float edge_raw(const TrainAgg &a, int i, int e, int &j)
+{
+    j = a.src[e];
+    float l = a.a_src[j] + a.a_dst[i];
+    if (a.edge_attr && a.v) {
+        const int id = a.eid[e];
+        const float *ea = id >= 0 ? a.edge_attr + (long long)id * a.edge_dim : a.loop_attr + (long long)i * a.edge_dim;
+        float t = 0.0f;
+        for (int d = 0; d < a.edge_dim; ++d) t = __builtin_fmaf(ea[d], a.v[d], t);
+        l += t;
+    }
+    return l;
+}
+
+__global__ __launch_bounds__(256) void agg_train_kernel(TrainAgg a)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.N) return;
+    const int beg = a.row_ptr[i], end = a.row_ptr[i + 1];
+    float m = -INFINITY;
+    for (int e = beg + lane; e < end; e += 64) { int j; float l = edge_raw(a, i, e, j); l = l > 0.f ? l : a.slope * l; m = fmaxf(m, l); }
+    m = wave_maxf(m);
+    float s = 0.0f;
+    for (int e = beg + lane; e < end; e += 64) { int j; float l = edge_raw(a, i, e, j); l = l > 0.f ? l : a.slope * l; s += expf(l - m); }
+    s = wave_sumf(s) + 1e-16f;                                   // PyG softmax
+    // H <= 1024: up to 16 columns per lane; softmax weights travel between lanes by shuffle only
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    for (int c0 = beg; c0 < end; c0 += 64) {
+        const int e = c0 + lane;
+        int j = 0;
+        float al = 0.0f, ald = 0.0f;
+        if (e < end) {
+            float l = edge_raw(a, i, e, j); l = l > 0.f ? l : a.slope * l;
+            al = expf(l - m) / s;
+            a.alpha[e] = al;                                      // saved for the backward (pre-dropout)
+            ald = al * keep_scale(a.p, a.seed, a.stream, (unsigned long long)e);   // attention dropout
+        }
+        const int cnt = min(64, end - c0);
+        for (int t = 0; t < cnt; ++t) {
+            const float at = __shfl(ald, t);
+            const int jt = __shfl(j, t);
+            const float *g = a.G + (long long)jt * a.H;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int c = lane + 64 * k;
+                if (c < a.H) acc[k] = __builtin_fmaf(at, g[c], acc[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = lane + 64 * k;
+        if (c < a.H) a.y[(long long)i * a.H + c] = acc[k] + a.bias[c];
+    }
+}
+
+// backward, per target i: dalpha'_e = <dY_i, g_j>; softmax + leaky-relu backward -> draw[e]; da_dst[i]
+struct AttBwdA {
+    const int *row_ptr, *src, *eid;
+    const float *loop_attr, *edge_attr, *v;
+    const float *a_src, *a_dst, *G, *alpha, *dY;
+    float *draw;        // (nnz) gradient of the pre-leaky-relu logit
+    float *da_dst;      // (N)
+    float slope, p;
+    unsigned long long seed;
+    unsigned stream;
+    int N, H, edge_dim;
+};
+
+__global__ __launch_bounds__(256) void att_bwd_target_kernel(AttBwdA a)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.N) return;
+    const int beg = a.row_ptr[i], end = a.row_ptr[i + 1];
+    TrainAgg t;   // view for edge_raw()
+    t.src = a.src; t.eid = a.eid; t.a_src = a.a_src; t.a_dst = a.a_dst; t.edge_attr = a.edge_attr;
+    t.loop_attr = a.loop_attr; t.v = a.v; t.edge_dim = a.edge_dim;
+    auto dalpha = [&](int e) -> float {                       // <dY_i, g_j> through the dropout mask
+        const int j = a.src[e];
+        float d = 0.0f;
+        for (int c = lane; c < a.H; c += 64)
+            d = __builtin_fmaf(a.dY[(long long)i * a.H + c], a.G[(long long)j * a.H + c], d);
+        return wave_sumf(d) * keep_scale(a.p, a.seed, a.stream, (unsigned long long)e);
+    };
+    float inner = 0.0f;                                       // sum_e alpha_e dalpha_e (wave-uniform)
+    for (int e = beg; e < end; ++e) inner += a.alpha[e] * dalpha(e);
+    float dd = 0.0f;
+    for (int e = beg; e < end; ++e) {
+        int j;
+        const float raw = edge_raw(t, i, e, j);
+        const float dl = a.alpha[e] * (dalpha(e) - inner);    // softmax backward
+        const float dr = raw > 0.0f ? dl : a.slope * dl;      // leaky-relu backward
+        if (lane == 0) a.draw[e] = dr;
+        dd += dr;
+    }
+    if (lane == 0) a.da_dst[i] = dd;
+}
+
+// backward, per source j (transposed CSR): dG_j = sum_e alpha'_e dY_tgt(e) + da_src[j] att_src + da_dst[j] att_dst
+struct AttBwdB {
+    const int *t_ptr, *t_entry, *tgt;
+    const float *alpha, *dY, *draw, *da_dst, *att_src, *att_dst;
+    float *dG;          // (N,H)
+    float *da_src;      // (N)
+    float p;
+    unsigned long long seed;
+    unsigned stream;
+    int N, H;
+};
+
+__global__ __launch_bounds__(256) void att_bwd_source_kernel(AttBwdB a)
+{
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= a.N) return;
+    const int beg = a.t_ptr[j], end = a.t_ptr[j + 1];
+    float das = 0.0f;
+    for (int t = beg; t < end; ++t) das += a.draw[a.t_entry[t]];
+    const float dad = a.da_dst[j];
+    for (int c = lane; c < a.H; c += 64) {
+        float acc = das * a.att_src[c] + dad * a.att_dst[c];
+        for (int t = beg; t < end; ++t) {
+            const int e = a.t_entry[t];
+            const float al = a.alpha[e] * keep_scale(a.p, a.seed, a.stream, (unsigned long long)e);
+            acc = __builtin_fmaf(al, a.dY[(long long)a.tgt[e] * a.H + c], acc);
+        }
+        a.dG[(long long)j * a.H + c] = acc;
+    }
+    if (lane == 0) a.da_src[j] = das;
+}
+
+// dv[d] = sum_e draw[e] * ea_e[d]  (edge term gradient), single workgroup, deterministic
+__global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restrict__ row_ptr,
+                                                            const int *__restrict__ eid,
+                                                            const int *__restrict__ tgt,
+                                                            const float *__restrict__ loop_attr,
+                                                            const float *__restrict__ edge_attr,
+                                                            const float *__restrict__ draw, int N, int edge_dim,
+                                                            float *__restrict__ dv)
+{
+    __shared__ double sh[256];
+    const int nnz = row_ptr[N];
+    for (int d = 0; d < edge_dim; ++d) {
+        double s = 0.0;
+        for (int e = threadIdx.x; e < nnz; e += 256) {
+            const int id = eid[e];
+            const float ea = id >= 0 ? edge_attr[(long long)id * edge_dim + d]
+                                     : loop_attr[(long long)tgt[e] * edge_dim + d];
+            s += (double)draw[e] * (double)ea;
+        }
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) dv[d] = (float)sh[0];
+        __syncthreads();
+    }
+}
+
+// v = W_edge^T att_edge (forward) and its backward: dW_edge[c,d] = dv[d] att_edge[c]; datt_edge[c] = sum_d dv[d] W_edge[c,d]
+__global__ __launch_bounds__(256) void edge_vec_kernel(const float *__restrict__ w_edge, const float *__restrict__ att_edge,
+                                                       int H, int edge_dim, float *__restrict__ v)
+{
+    const int d = threadIdx.x;
+    if (d >= edge_dim) return;
+    float s = 0.0f;
+    for (int c = 0; c < H; ++c) s = __builtin_fmaf(w_edge[(long long)c * edge_dim + d], att_edge[c], s);
+    v[d] = s;
+}
+__global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const float *__restrict__ w_edge, const float *__restrict__ att_edge,
+                                                           const float *__restrict__ dv, int H, int edge_dim,
+                                                           float *__restrict__ dw_edge, float *__restrict__ datt_edge)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    float s = 0.0f;
+    for (int d = 0; d < edge_dim; ++d) {
+        dw_edge[(long long)c * edge_dim + d] = dv[d] * att_edge[c];
+        s = __builtin_fmaf(dv[d], w_edge[(long long)c * edge_dim + d], s);
+    }
+    datt_edge[c] = s;
+}
+
+// transposed CSR (entries grouped by source) from the forward CSR
+__global__ __launch_bounds__(256) void tcsr_count_kernel(const int *__restrict__ row_ptr, const int *__restrict__ src,
+                                                         int N, int *__restrict__ cnt, int *__restrict__ tgt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) { atomicAdd(&cnt[src[e]], 1); tgt[e] = i; }
+}
+__global__ __launch_bounds__(1024) void tcsr_scan_kernel(const int *__restrict__ cnt, int N, int *__restrict__ t_ptr)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, chunk = (N + 1023) / 1024;
+    const int b = tid * chunk, e = min(b + chunk, N);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = b; i < e; ++i) { t_ptr[i] = run; run += cnt[i]; }
+    if (tid == 1023) t_ptr[N] = part[1023];
+}
+__global__ __launch_bounds__(256) void tcsr_fill_kernel(const int *__restrict__ row_ptr, const int *__restrict__ src,
+                                                        int N, const int *__restrict__ t_ptr, int *__restrict__ cursor,
+                                                        int *__restrict__ t_entry)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+        const int j = src[e];
+        t_entry[t_ptr[j] + atomicAdd(&cursor[j], 1)] = e;
+    }
+}
+__global__ __launch_bounds__(256) void tcsr_sort_kernel(const int *__restrict__ t_ptr, int N, int *__restrict__ t_entry)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const int b = t_ptr[j], e = t_ptr[j + 1];
+    for (int a = b + 1; a < e; ++a) {
+        const int v = t_entry[a];
+        int c = a - 1;
+        while (c >= b && t_entry[c] > v) { t_entry[c + 1] = t_entry[c]; --c; }
+        t_entry[c + 1] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// triplet loss forward + backward (trainer.py:62-68): one wave per triplet
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void triplet_kernel(const float *__restrict__ emb, const long long *__restrict__ ia,
+                                                      const long long *__restrict__ ip, const long long *__restrict__ in_,
+                                                      int T, int D, float margin, float scale,
+                                                      float *__restrict__ per_triplet, float *__restrict__ grad)
+{
+    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float *a = emb + ia[t] * D, *p = emb + ip[t] * D, *n = emb + in_[t] * D;
+    float dp = 0.f, dn = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float x = a[c] - p[c], y = a[c] - n[c];
+        dp = __builtin_fmaf(x, x, dp);
+        dn = __builtin_fmaf(y, y, dn);
+    }
+    dp = wave_sumf(dp); dn = wave_sumf(dn);
+    const float l = dp - dn + margin;
+    if (lane == 0) per_triplet[t] = l > 0.0f ? l : 0.0f;
+    if (grad && l > 0.0f) {
+        const float g = 2.0f * scale / (float)T;              // d(mean relu)/d(dist) * 2(a - .)
+        float *ga = grad + ia[t] * D, *gp = grad + ip[t] * D, *gn = grad + in_[t] * D;
+        for (int c = lane; c < D; c += 64) {
+            const float av = a[c], pv = p[c], nv = n[c];
+            atomicAdd(&ga[c], g * (nv - pv));
+            atomicAdd(&gp[c], -g * (av - pv));
+            atomicAdd(&gn[c], g * (av - nv));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void triplet_reduce_kernel(const float *__restrict__ per_triplet, int T, float scale,
+                                                             float *__restrict__ loss)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < T; t += 256) s += (double)per_triplet[t];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) loss[0] = (float)(sh[0] / T) * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+constexpr int SPLITK_SLABS = 16;
+constexpr int COLRED_MAXR = 64;
+
+struct TrainWs {
+    // saved by the forward
+    size_t z0, mean0, invstd0, h, g, a_src, a_dst, alpha, y, mean, invstd, vvec;
+    // backward scratch
+    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, total;
+    size_t nh, nn, hh, nz;
+};
+
+TrainWs train_ws(const NscGatModel *m, int N, int nnz)
+{
+    TrainWs w;
+    const int H = m->hidden, L = m->n_layers;
+    w.nh = align256((size_t)N * H * 4); w.nn = align256((size_t)N * 4); w.hh = align256((size_t)H * 4);
+    w.nz = align256((size_t)nnz * 4);
+    size_t o = 0;
+    w.z0 = o; o += w.nh;
+    w.mean0 = o; o += w.hh;
+    w.invstd0 = o; o += w.hh;
+    w.h = o; o += w.nh * (L + 1);
+    w.g = o; o += w.nh * L;
+    w.a_src = o; o += w.nn * L;
+    w.a_dst = o; o += w.nn * L;
+    w.alpha = o; o += w.nz * L;
+    w.y = o; o += w.nh * L;
+    w.mean = o; o += w.hh * L;
+    w.invstd = o; o += w.hh * L;
+    w.vvec = o; o += 256 * L;
+    w.dh = o; o += w.nh;
+    w.dh2 = o; o += w.nh;
+    w.dv = o; o += w.nh;
+    w.dg = o; o += w.nh;
+    w.draw = o; o += w.nz;
+    w.da_src = o; o += w.nn;
+    w.da_dst = o; o += w.nn;
+    w.s1 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
+    w.s2 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
+    w.dvvec = o; o += 256;
+    const size_t big = (size_t)std::max(m->in_dim, m->out_dim) * H;
+    w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);
+    w.colpart = o; o += align256((size_t)COLRED_MAXR * std::max(std::max(H, m->out_dim), m->in_dim) * 2 * 8);
+    w.total = o;
+    return w;
+}
+
+template <bool AKM, bool BKM>
+void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
+          const float *bias, int accumulate, int splits, float *slabs)
+{
+    dim3 grid((N + 63) / 64, (M + 31) / 32, splits);
+    if (splits <= 1) {
+        hipLaunchKernelGGL((gemm_gen_kernel<AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, K, K, C, ldc,
+                           0LL, bias, accumulate);
+    } else {
+        int kchunk = (K + splits - 1) / splits;
+        kchunk = (kchunk + 63) / 64 * 64;
+        hipLaunchKernelGGL((gemm_gen_kernel<AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, K, kchunk, slabs,
+                           N, (long long)M * N, static_cast<const float *>(nullptr), 0);
+        const long long MN = (long long)M * N;      // requires ldc == N
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C);
+    }
+}
+
+void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
+               int N, int C, double *part, int mode, float eps, float momentum, float *out_a, float *out_b,
+               float *run_mean, float *run_var)
+{
+    int R = (N + 63) / 64;
+    if (R > COLRED_MAXR) R = COLRED_MAXR;
+    if (R < 1) R = 1;
+    const int rows = (N + R - 1) / R;
+    hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, R, C, mode, N, eps, momentum,
+                       out_a, out_b, run_mean, run_var);
+}
+
+inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
+
+int check_train(const NscGatModel *m, const NscGraph *g)
+{
+    if (!m || !g) return NSC_EINVAL;
+    if (m->n_layers < 1 || m->n_layers > NSC_GAT_MAX_LAYERS) return NSC_EUNSUPPORTED;
+    if (m->hidden < 16 || m->hidden > 1024 || (m->hidden & 15)) return NSC_EUNSUPPORTED;
+    if (m->in_dim < 16 || (m->in_dim & 15) || m->out_dim < 4 || (m->out_dim & 3)) return NSC_EUNSUPPORTED;
+    if (m->edge_dim < 0 || m->edge_dim > NSC_GAT_MAX_EDGE_DIM) return NSC_EUNSUPPORTED;
+    if (m->residual && m->in_dim != m->out_dim) return NSC_EUNSUPPORTED;   // residual_proj: inference only so far
+    if (!g->row_ptr || !g->src || !g->eid) return NSC_EINVAL;
+    return NSC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nsc_graph_transpose_workspace_bytes(int32_t n_nodes) { return n_nodes > 0 ? align256((size_t)n_nodes * 4) * 2 : 0; }
+
+int nsc_graph_transpose(const NscGraph *g, int32_t *t_ptr, int32_t *t_entry, int32_t *tgt, void *ws, size_t ws_bytes,
+                        void *stream_)
+{
+    if (!g || !t_ptr || !t_entry || !tgt || !g->row_ptr || !g->src) return NSC_EINVAL;
+    const int N = g->n_nodes;
+    if (N <= 0) return NSC_OK;
+    const size_t need = nsc_graph_transpose_workspace_bytes(N);
+    if (!ws || ws_bytes < need) return NSC_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    int *cnt = static_cast<int *>(ws);
+    int *cursor = reinterpret_cast<int *>(static_cast<char *>(ws) + need / 2);
+    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return NSC_ELAUNCH;
+    hipLaunchKernelGGL(tcsr_count_kernel, dim3(blocks(N)), dim3(256), 0, st, g->row_ptr, g->src, N, cnt, tgt);
+    hipLaunchKernelGGL(tcsr_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, N, t_ptr);
+    hipLaunchKernelGGL(tcsr_fill_kernel, dim3(blocks(N)), dim3(256), 0, st, g->row_ptr, g->src, N, t_ptr, cursor, t_entry);
+    hipLaunchKernelGGL(tcsr_sort_kernel, dim3(blocks(N)), dim3(256), 0, st, t_ptr, N, t_entry);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+size_t nsc_gat_train_workspace_bytes(const NscGatModel *m, const NscGraph *g)
+{
+    if (check_train(m, g) != NSC_OK || g->n_nodes <= 0) return 0;
+    return train_ws(m, g->n_nodes, g->nnz).total;
+}
+
+int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
+                          const NscGatTrainCfg *cfg, float *out, void *ws, size_t ws_bytes, void *stream_)
+{
+    int stt = check_train(m, g);
+    if (stt != NSC_OK) return stt;
+    if (!cfg || !x || !out) return NSC_EINVAL;
+    const int N = g->n_nodes, H = m->hidden, L = m->n_layers;
+    if (N == 0) return NSC_OK;
+    const TrainWs w = train_ws(m, N, g->nnz);
+    if (!ws || ws_bytes < w.total) return NSC_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    char *b = static_cast<char *>(ws);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
+    double *colpart = reinterpret_cast<double *>(b + w.colpart);
+    const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
+    const long long NH = (long long)N * H;
+    const int upd = cfg->update_running_stats;
+
+    // input_proj (bias) -> z0 ; BatchNorm(batch stats) ; ReLU                 model.py:116-118
+    gemm<false, false>(st, x, m->in_dim, m->in_w, m->in_dim, N, H, m->in_dim, F(w.z0), H, m->in_b, 0, 1, nullptr);
+    colreduce(st, F(w.z0), nullptr, F(w.z0), nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum,
+              F(w.mean0), F(w.invstd0), upd ? const_cast<float *>(m->in_bn_mean) : nullptr,
+              upd ? const_cast<float *>(m->in_bn_var) : nullptr);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(blocks(NH)), dim3(256), 0, st, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
+                       m->in_bn_b, 1, 0.0f, 0ull, 0u, static_cast<const float *>(nullptr), NH, H, F(w.h));
+
+    for (int l = 0; l < L; ++l) {
+        const NscGatLayer &Ly = m->layers[l];
+        float *hin = F(w.h + w.nh * l), *hout = F(w.h + w.nh * (l + 1));
+        float *G = F(w.g + w.nh * l), *as = F(w.a_src + w.nn * l), *ad = F(w.a_dst + w.nn * l);
+        float *alpha = F(w.alpha + w.nz * l), *y = F(w.y + w.nh * l);
+        float *mean = F(w.mean + w.hh * l), *invstd = F(w.invstd + w.hh * l), *vv = F(w.vvec + 256 * l);
+        gemm<false, false>(st, hin, H, Ly.lin_w, H, N, H, H, G, H, nullptr, 0, 1, nullptr);
+        hipLaunchKernelGGL(att_dots_kernel, dim3((N + 3) / 4), dim3(256), 0, st, G, Ly.att_src, Ly.att_dst, N, H, as, ad);
+        if (use_edge)
+            hipLaunchKernelGGL(edge_vec_kernel, dim3(1), dim3(256), 0, st, Ly.lin_edge_w, Ly.att_edge, H, m->edge_dim, vv);
+        TrainAgg a;
+        a.row_ptr = g->row_ptr; a.src = g->src; a.eid = g->eid;
+        a.loop_attr = use_edge ? g->loop_attr : nullptr;
+        a.edge_attr = use_edge ? edge_attr : nullptr;
+        a.v = use_edge ? vv : nullptr;
+        a.a_src = as; a.a_dst = ad; a.G = G; a.bias = Ly.bias; a.alpha = alpha; a.y = y;
+        a.slope = m->negative_slope; a.p = cfg->dropout_p; a.seed = cfg->seed; a.stream = 100u + l;
+        a.N = N; a.H = H; a.edge_dim = m->edge_dim;
+        hipLaunchKernelGGL(agg_train_kernel, dim3((N + 3) / 4), dim3(256), 0, st, a);
+        colreduce(st, y, nullptr, y, nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum, mean, invstd,
+                  upd ? const_cast<float *>(Ly.bn_mean) : nullptr, upd ? const_cast<float *>(Ly.bn_var) : nullptr);
+        const int act = (l < L - 1);                                           // model.py:135-137
+        const float *resid = (m->residual && l > 0 && l < L - 1) ? hin : nullptr;   // model.py:140-141
+        hipLaunchKernelGGL(bn_act_kernel, dim3(blocks(NH)), dim3(256), 0, st, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
+                           act ? cfg->dropout_p : 0.0f, cfg->seed, 200u + l, resid, NH, H, hout);
+    }
+    // output_proj + input residual                                             model.py:144-151
+    gemm<false, false>(st, F(w.h + w.nh * L), H, m->out_w, H, N, m->out_dim, H, out, m->out_dim, m->out_b, 0, 1, nullptr);
+    if (m->residual) {
+        const long long tot = (long long)N * m->out_dim;
+        hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(tot)), dim3(256), 0, st, out, x, tot);
+    }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
+                     const NscGatTrainCfg *cfg, const float *grad_out, const NscGatGrads *gr, void *ws,
+                     size_t ws_bytes, void *stream_)
+{
+    int stt = check_train(m, g);
+    if (stt != NSC_OK) return stt;
+    if (!cfg || !x || !grad_out || !gr || !g->t_ptr || !g->t_entry || !g->tgt) return NSC_EINVAL;
+    const int N = g->n_nodes, H = m->hidden, L = m->n_layers, Dout = m->out_dim, Din = m->in_dim;
+    if (N == 0) return NSC_OK;
+    const TrainWs w = train_ws(m, N, g->nnz);
+    if (!ws || ws_bytes < w.total) return NSC_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    char *b = static_cast<char *>(ws);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
+    double *colpart = reinterpret_cast<double *>(b + w.colpart);
+    float *slabs = F(w.slabs);
+    const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
+    const long long NH = (long long)N * H;
+    const int splits = N >= 512 ? SPLITK_SLABS : 1;
+
+    // output_proj: out = h_L W_out^T + b (+ x)
+    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr);
+    gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, 0, splits, slabs);
+    float *dh = F(w.dh), *dh_prev = F(w.dh2);
+    gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, nullptr);   // dh_L = dOut W_out
+    if (gr->x) {   // gradient wrt the input features through the residual connection only
+        if (hipMemcpyAsync(gr->x, grad_out, (size_t)N * Din * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+    }
+
+    for (int l = L - 1; l >= 0; --l) {
+        const NscGatLayer &Ly = m->layers[l];
+        const NscGatGradLayer &Gl = gr->layers[l];
+        float *hin = F(w.h + w.nh * l);
+        float *G = F(w.g + w.nh * l), *as = F(w.a_src + w.nn * l), *ad = F(w.a_dst + w.nn * l);
+        float *alpha = F(w.alpha + w.nz * l), *y = F(w.y + w.nh * l);
+        float *mean = F(w.mean + w.hh * l), *invstd = F(w.invstd + w.hh * l), *vv = F(w.vvec + 256 * l);
+        float *dv = F(w.dv), *dG = F(w.dg), *s1 = F(w.s1), *s2 = F(w.s2);
+        const int act = (l < L - 1);
+        const bool has_res = (m->residual && l > 0 && l < L - 1);
+        // h_{l+1} = drop(relu(bn(y))) [+ h_l]  ->  dV, BatchNorm backward -> dY (in place in dv)
+        hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
+                           act ? cfg->dropout_p : 0.0f, cfg->seed, 200u + l, NH, H, dv);
+        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
+        if (hipMemcpyAsync(Gl.bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+        if (hipMemcpyAsync(Gl.bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, y, mean, invstd, Ly.bn_w, s1, s2, NH, H, N, dv);
+        float *dY = dv;
+        // conv bias
+        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr);
+        // attention backward
+        AttBwdA A;
+        A.row_ptr = g->row_ptr; A.src = g->src; A.eid = g->eid;
+        A.loop_attr = use_edge ? g->loop_attr : nullptr; A.edge_attr = use_edge ? edge_attr : nullptr;
+        A.v = use_edge ? vv : nullptr;
+        A.a_src = as; A.a_dst = ad; A.G = G; A.alpha = alpha; A.dY = dY;
+        A.draw = F(w.draw); A.da_dst = F(w.da_dst);
+        A.slope = m->negative_slope; A.p = cfg->dropout_p; A.seed = cfg->seed; A.stream = 100u + l;
+        A.N = N; A.H = H; A.edge_dim = m->edge_dim;
+        hipLaunchKernelGGL(att_bwd_target_kernel, dim3((N + 3) / 4), dim3(256), 0, st, A);
+        AttBwdB Bk;
+        Bk.t_ptr = g->t_ptr; Bk.t_entry = g->t_entry; Bk.tgt = g->tgt;
+        Bk.alpha = alpha; Bk.dY = dY; Bk.draw = F(w.draw); Bk.da_dst = F(w.da_dst);
+        Bk.att_src = Ly.att_src; Bk.att_dst = Ly.att_dst; Bk.dG = dG; Bk.da_src = F(w.da_src);
+        Bk.p = cfg->dropout_p; Bk.seed = cfg->seed; Bk.stream = 100u + l; Bk.N = N; Bk.H = H;
+        hipLaunchKernelGGL(att_bwd_source_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Bk);
+        // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
+        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr);
+        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr);
+        if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
+            if (use_edge) {
+                hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(1), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt, g->loop_attr,
+                                   edge_attr, F(w.draw), N, m->edge_dim, F(w.dvvec));
+                hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(blocks(H)), dim3(256), 0, st, Ly.lin_edge_w, Ly.att_edge, F(w.dvvec),
+                                   H, m->edge_dim, Gl.lin_edge_w, Gl.att_edge);
+            } else {
+                if (hipMemsetAsync(Gl.lin_edge_w, 0, (size_t)H * m->edge_dim * 4, st) != hipSuccess) return NSC_ELAUNCH;
+                if (hipMemsetAsync(Gl.att_edge, 0, (size_t)H * 4, st) != hipSuccess) return NSC_ELAUNCH;
+            }
+        }
+        // g = h_l W^T :  dW = dG^T h_l ,  dh_l = dG W (+ residual path)
+        gemm<true, true>(st, dG, H, hin, H, H, H, N, Gl.lin_w, H, nullptr, 0, splits, slabs);
+        gemm<false, true>(st, dG, H, Ly.lin_w, H, N, H, H, dh_prev, H, nullptr, 0, 1, nullptr);
+        if (has_res) hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh_prev, dh, NH);
+        float *t = dh; dh = dh_prev; dh_prev = t;
+    }
+    // h_0 = relu(bn(z0)),  z0 = x W_in^T + b_in
+    float *dv = F(w.dv), *s1 = F(w.s1), *s2 = F(w.s2);
+    hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
+                       m->in_bn_b, 1, 0.0f, 0ull, 0u, NH, H, dv);
+    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
+    if (hipMemcpyAsync(gr->in_bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+    if (hipMemcpyAsync(gr->in_bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, s1, s2,
+                       NH, H, N, dv);
+    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr);
+    gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, 0, splits, slabs);
+    if (gr->x) {   // + dZ0 W_in
+        gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+size_t nsc_triplet_workspace_bytes(int32_t n_triplets) { return n_triplets > 0 ? align256((size_t)n_triplets * 4) : 0; }
+
+int nsc_triplet_loss(const float *emb, const int64_t *anchors, const int64_t *positives, const int64_t *negatives,
+                     int32_t T, int32_t N, int32_t D, float margin, float scale, float *loss, float *grad_emb,
+                     void *ws, size_t ws_bytes, void *stream_)
+{
+    if (T < 0 || N < 0 || D < 1) return NSC_EINVAL;
+    if (!loss) return NSC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (grad_emb && hipMemsetAsync(grad_emb, 0, (size_t)N * D * 4, st) != hipSuccess) return NSC_ELAUNCH;
+    if (T == 0) return hipMemsetAsync(loss, 0, 4, st) == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+    if (!emb || !anchors || !positives || !negatives) return NSC_EINVAL;
+    if (!ws || ws_bytes < nsc_triplet_workspace_bytes(T)) return NSC_EWORKSPACE;
+    float *per = static_cast<float *>(ws);
+    hipLaunchKernelGGL(triplet_kernel, dim3((T + 3) / 4), dim3(256), 0, st, emb, reinterpret_cast<const long long *>(anchors),
+                       reinterpret_cast<const long long *>(positives), reinterpret_cast<const long long *>(negatives), T, D,
+                       margin, scale, per, grad_emb);
+    hipLaunchKernelGGL(triplet_reduce_kernel, dim3(1), dim3(256), 0, st, per, T, scale, loss);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+}  // extern "C"

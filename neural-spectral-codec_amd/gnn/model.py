@@ -60,6 +60,25 @@ class GraphCSR:
                                        _lib.stream_ptr(dev))
         _lib.check(st, "nsc_graph_build_csr")
 
+        self.t_ptr = self.t_entry = self.tgt = None
+
+    def ensure_transpose(self):
+        """Entries grouped by source (nsc_graph_transpose); the backward needs it, built once."""
+        if self.t_ptr is not None:
+            return
+        dev = self.row_ptr.device
+        L = _lib.lib()
+        self.t_ptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+        self.t_entry = torch.empty(self.capacity, dtype=torch.int32, device=dev)
+        self.tgt = torch.empty(self.capacity, dtype=torch.int32, device=dev)
+        nbytes = L.nsc_graph_transpose_workspace_bytes(self.n_nodes)
+        ws = _ws(dev, nbytes, "graph")
+        g = self.struct()
+        with torch.cuda.device(dev):
+            st = L.nsc_graph_transpose(C.byref(g), _lib.ptr(self.t_ptr), _lib.ptr(self.t_entry),
+                                       _lib.ptr(self.tgt), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_graph_transpose")
+
     def struct(self) -> _lib.Graph:
         g = _lib.Graph()
         g.n_nodes = self.n_nodes
@@ -68,7 +87,69 @@ class GraphCSR:
         g.src = self.src.data_ptr()
         g.eid = self.eid.data_ptr()
         g.loop_attr = self.loop_attr.data_ptr() if self.loop_attr is not None else None
+        if self.t_ptr is not None:
+            g.t_ptr, g.t_entry, g.tgt = self.t_ptr.data_ptr(), self.t_entry.data_ptr(), self.tgt.data_ptr()
         return g
+
+
+class _GatTrainFunction(torch.autograd.Function):
+    """model.train(); model(data) with autograd: nsc_gat_forward_train / nsc_gat_backward."""
+
+    @staticmethod
+    def forward(ctx, gnn, x, csr, dropout_p, seed, *params):
+        L = _lib.lib()
+        dev = x.device
+        m = gnn._model_struct()
+        csr.ensure_transpose()
+        g = csr.struct()
+        cfg = _lib.GatTrainCfg()
+        cfg.dropout_p, cfg.bn_momentum = float(dropout_p), float(gnn.input_norm.momentum or 0.1)
+        cfg.seed, cfg.update_running_stats = int(seed), 1
+        n = int(x.shape[0])
+        out = torch.empty((n, gnn.output_dim), dtype=torch.float32, device=dev)
+        nbytes = L.nsc_gat_train_workspace_bytes(C.byref(m), C.byref(g))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # holds the saved activations
+        with torch.cuda.device(dev):
+            st = L.nsc_gat_forward_train(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
+                                         C.byref(cfg), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_gat_forward_train")
+        for bn in [gnn.input_norm] + list(gnn.batch_norms):
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        ctx.gnn, ctx.csr, ctx.cfg, ctx.ws, ctx.nbytes, ctx.x = gnn, csr, cfg, ws, nbytes, x
+        ctx.need_x = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gnn, csr, x = ctx.gnn, ctx.csr, ctx.x
+        L = _lib.lib()
+        dev = x.device
+        m = gnn._model_struct()
+        g = csr.struct()
+        params = gnn._train_params()
+        grads = [torch.empty_like(p) for p in params]
+        gs = _lib.GatGrads()
+        it = iter(grads)
+        gs.in_w, gs.in_b = next(it).data_ptr(), next(it).data_ptr()
+        gs.in_bn_w, gs.in_bn_b = next(it).data_ptr(), next(it).data_ptr()
+        gs.out_w, gs.out_b = next(it).data_ptr(), next(it).data_ptr()
+        for l, conv in enumerate(gnn.convs):
+            gl = gs.layers[l]
+            gl.lin_w, gl.att_src, gl.att_dst = next(it).data_ptr(), next(it).data_ptr(), next(it).data_ptr()
+            if conv.lin_edge is not None:
+                gl.lin_edge_w, gl.att_edge = next(it).data_ptr(), next(it).data_ptr()
+            gl.bias, gl.bn_w, gl.bn_b = next(it).data_ptr(), next(it).data_ptr(), next(it).data_ptr()
+        gx = torch.empty_like(x) if ctx.need_x else None
+        gs.x = gx.data_ptr() if gx is not None else None
+        go = grad_out.contiguous().float()
+        with torch.cuda.device(dev):
+            st = L.nsc_gat_backward(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
+                                    C.byref(ctx.cfg), _lib.ptr(go), C.byref(gs), _lib.ptr(ctx.ws), ctx.nbytes,
+                                    _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_gat_backward")
+        ctx.ws = None
+        return (None, gx, None, None, None, *grads)
 
 
 class SpectralGNN(nn.Module):
@@ -173,15 +254,36 @@ class SpectralGNN(nn.Module):
             ly.bn_mean, ly.bn_var = p(bn.running_mean), p(bn.running_var)
         return m
 
+    def _train_params(self):
+        """Parameters in the order NscGatGrads lists them."""
+        ps = [self.input_proj.weight, self.input_proj.bias, self.input_norm.weight, self.input_norm.bias,
+              self.output_proj.weight, self.output_proj.bias]
+        for conv, bn in zip(self.convs, self.batch_norms):
+            ps += [conv.lin_src.weight, conv.att_src, conv.att_dst]
+            if conv.lin_edge is not None:
+                ps += [conv.lin_edge.weight, conv.att_edge]
+            ps += [conv.bias, bn.weight, bn.bias]
+        return ps
+
+    def _run_train(self, data, use_edge_attr: bool):
+        """model.train() forward with autograd (trainer.py:205): batch-statistics BatchNorm, feature and
+        attention dropout (counter-based masks seeded from torch's CPU generator)."""
+        x = data.x
+        _lib.require_cuda(x, "data.x")
+        if self.residual_proj is not None:
+            raise NotImplementedError("training with residual_proj (input_dim != output_dim) is not supported")
+        x = x.to(torch.float32).contiguous()
+        csr = self._csr(data, use_edge_attr)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout > 0 else 0
+        return _GatTrainFunction.apply(self, x, csr, float(self.dropout), seed, *self._train_params())
+
     def _run(self, data, use_edge_attr: bool, want_alpha: bool):
         x = data.x
         _lib.require_cuda(x, "data.x")
         if self.input_proj.weight.device != x.device:
             raise _lib.NscError("SpectralGNN and data must be on the same HIP device")
         if self.training:
-            raise NotImplementedError(
-                "training-mode forward (batch-stat BatchNorm, dropout, autograd) is not on the MI355X "
-                "path yet; call model.eval() for the inference forward (pipeline.py:253-256)")
+            raise _lib.NscError("forward_with_attention is an inference helper: call model.eval() first")
         dev = x.device
         x = x.detach().to(torch.float32).contiguous()
         n = int(x.shape[0])
@@ -206,6 +308,8 @@ class SpectralGNN(nn.Module):
         """model.py:96-153: data.x (N,in), data.edge_index (2,E), optional data.edge_attr (E,edge_dim)."""
         edge_attr = getattr(data, 'edge_attr', None)
         use_edge = edge_attr is not None and self.edge_dim is not None       # :126
+        if self.training:
+            return self._run_train(data, use_edge)
         out, _, _ = self._run(data, use_edge, False)
         return out
 

@@ -1,0 +1,103 @@
+"""Training step of the GNN on MI355X: TripletLoss + the per-batch step of GNNTrainer.train_epoch.
+
+Mirrors reference src/gnn/trainer.py: ``TripletLoss`` (:27-68) and the inner loop of
+``GNNTrainer.train_epoch`` (:186-231: full-graph forward per 1 024-triplet batch, loss / 4,
+backward, Adam step every 4 batches).  Triplet mining (src/gnn/triplet_miner.py) stays on the host
+as in the reference and is not part of this package.
+"""
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .. import _lib
+
+_WS = {}
+
+
+class _TripletFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, ia, ip, in_, margin, scale):
+        L = _lib.lib()
+        dev = emb.device
+        emb = emb.contiguous()
+        n, d, t = int(emb.shape[0]), int(emb.shape[1]), int(ia.numel())
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(emb) if emb.requires_grad else None
+        nbytes = L.nsc_triplet_workspace_bytes(t)
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            st = L.nsc_triplet_loss(_lib.ptr(emb), _lib.ptr(ia), _lib.ptr(ip), _lib.ptr(in_), t, n, d,
+                                    float(margin), float(scale), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws),
+                                    nbytes, _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_triplet_loss")
+        ctx.grad = grad
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g if ctx.grad is not None else None), None, None, None, None, None
+
+
+class TripletLoss(nn.Module):
+    """L(a,p,n) = mean(relu(|a-p|^2 - |a-n|^2 + margin))           trainer.py:27-68"""
+
+    def __init__(self, margin: float = 0.1):
+        super().__init__()
+        self.margin = margin
+
+    def forward_indexed(self, embeddings: torch.Tensor, anchor_idx, positive_idx, negative_idx,
+                        scale: float = 1.0) -> torch.Tensor:
+        """Fused gather + loss (+ gradient): embeddings (N,D), three index vectors (T,)."""
+        _lib.require_cuda(embeddings, "embeddings")
+        dev = embeddings.device
+        idx = [torch.as_tensor(np.asarray(i) if not isinstance(i, torch.Tensor) else i).to(
+            device=dev, dtype=torch.int64).contiguous() for i in (anchor_idx, positive_idx, negative_idx)]
+        return _TripletFn.apply(embeddings.float(), idx[0], idx[1], idx[2], self.margin, scale)
+
+    def forward(self, anchors: torch.Tensor, positives: torch.Tensor, negatives: torch.Tensor) -> torch.Tensor:
+        """Reference signature: three already-gathered (T,D) tensors."""
+        t = int(anchors.shape[0])
+        emb = torch.cat([anchors, positives, negatives], 0)
+        ar = torch.arange(t, device=emb.device, dtype=torch.int64)
+        return self.forward_indexed(emb, ar, ar + t, ar + 2 * t)
+
+
+class GNNTrainer:
+    """The optimisation step of reference GNNTrainer (trainer.py:71-236) without logging, mining,
+    validation and checkpoint plumbing: Adam(lr, weight_decay) over the model parameters, TripletLoss,
+    gradient accumulation over ``accumulation_steps`` batches of ``batch_size`` triplets."""
+
+    def __init__(self, model: nn.Module, device: str = 'cuda', learning_rate: float = 5e-4,
+                 weight_decay: float = 1e-5, margin: float = 0.1, batch_size: int = 1024,
+                 accumulation_steps: int = 4):
+        self.model = model.to(device)
+        self.device = device
+        self.optimizer = optim.Adam(model.parameters(), lr=learning_rate, weight_decay=weight_decay)  # :115-119
+        self.criterion = TripletLoss(margin=margin)                                                   # :121
+        self.batch_size, self.accumulation_steps = batch_size, accumulation_steps
+        self.global_step = 0
+
+    def train_batches(self, graph, triplets: Sequence) -> float:
+        """trainer.py:186-231 for an (n,3) array of (anchor, positive, negative) triplets."""
+        self.model.train()
+        triplets = np.asarray(triplets)
+        n_batches = (len(triplets) + self.batch_size - 1) // self.batch_size
+        losses = []
+        self.optimizer.zero_grad()
+        for b in range(n_batches):
+            bt = triplets[b * self.batch_size:(b + 1) * self.batch_size]
+            embeddings = self.model(graph)                                                    # :205
+            loss = self.criterion.forward_indexed(embeddings, bt[:, 0], bt[:, 1], bt[:, 2],
+                                                  scale=1.0 / self.accumulation_steps)        # :207-212
+            loss.backward()                                                                   # :213
+            losses.append(loss.detach())
+            self.global_step += 1
+            if (b + 1) % self.accumulation_steps == 0 or (b + 1) == n_batches:                # :219-221
+                self.optimizer.step()
+                self.optimizer.zero_grad()
+        if not losses:
+            return 0.0
+        return float(torch.stack(losses).mean().item() * self.accumulation_steps)

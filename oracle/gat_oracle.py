@@ -48,8 +48,9 @@ def gatconv_reference(x, edge_index, edge_attr, lin_w, att_src, att_dst, lin_edg
     if ea is not None and lin_edge_w is not None:
         logit = logit + ((ea @ lin_edge_w.t()) * att_edge.view(1, -1)).sum(-1)
     logit = F.leaky_relu(logit, negative_slope)
-    m = torch.full((n,), float("-inf"), dtype=x.dtype).scatter_reduce(0, i, logit, "amax", include_self=True)
-    p = torch.exp(logit - m[i])
+    m = torch.full((n,), float("-inf"), dtype=x.dtype).scatter_reduce(0, i, logit.detach(), "amax",
+                                                                      include_self=True)
+    p = torch.exp(logit - m[i])                       # the max shift carries no gradient (softmax identity)
     den = torch.zeros(n, dtype=x.dtype).index_add_(0, i, p)
     alpha = p / (den[i] + 1e-16)
     out = torch.zeros_like(h).index_add_(0, i, alpha.unsqueeze(1) * h[j])
@@ -106,17 +107,11 @@ def _bn(x, bn, training):
     return (x - mean) / torch.sqrt(var + bn.eps) * bn.weight + bn.bias
 
 
-def forward_reference(model, data, training=False):
-    """src/gnn/model.py:96-153 with the module's own parameters, on the CPU in float32.
-    training=True uses batch statistics in BatchNorm and NO dropout (dropout is stochastic and
-    unseeded in the reference; parity runs use dropout=0)."""
-    gnn = getattr(model, "gnn", model)                                  # LocalUpdateGNN wrapper :230
-    sd = {k: v.detach().cpu().float() for k, v in gnn.state_dict().items()}
-    x = data.x.detach().cpu().float()
-    ei = data.edge_index.detach().cpu()
-    ea = getattr(data, "edge_attr", None)
-    ea = ea.detach().cpu().float() if ea is not None else None
-    use_edge = ea is not None and gnn.edge_dim is not None               # :126
+def forward_from_state(sd, gnn_cfg, x, ei, ea, training=False):
+    """src/gnn/model.py:96-153 from a state dict (tensors may require grad -> torch autograd gives
+    the reference gradients).  gnn_cfg = (n_layers, residual, edge_dim)."""
+    n_layers, residual, edge_dim = gnn_cfg
+    use_edge = ea is not None and edge_dim is not None                   # :126
 
     class _B:                                                            # tiny BN view over the state dict
         def __init__(self, prefix):
@@ -127,7 +122,6 @@ def forward_reference(model, data, training=False):
     x_input = x
     h = x @ sd["input_proj.weight"].t() + sd["input_proj.bias"]          # :116
     h = F.relu(_bn(h, _B("input_norm"), training))                       # :117-118
-    n_layers = gnn.n_layers
     for l in range(n_layers):
         h_prev = h
         pre = f"convs.{l}."
@@ -138,15 +132,59 @@ def forward_reference(model, data, training=False):
         h = _bn(h, _B(f"batch_norms.{l}"), training)                     # :132
         if l < n_layers - 1:
             h = F.relu(h)                                                # :135-137 (dropout off)
-        if gnn.residual and 0 < l < n_layers - 1:
+        if residual and 0 < l < n_layers - 1:
             h = h + h_prev                                               # :140-141
     out = h @ sd["output_proj.weight"].t() + sd["output_proj.bias"]      # :144
-    if gnn.residual:
+    if residual:
         if "residual_proj.weight" in sd:
             out = out + x_input @ sd["residual_proj.weight"].t() + sd["residual_proj.bias"]
         else:
             out = out + x_input                                          # :147-151
     return out
+
+
+def forward_reference(model, data, training=False):
+    """src/gnn/model.py:96-153 with the module's own parameters, on the CPU in float32.
+    training=True uses batch statistics in BatchNorm and NO dropout (dropout is stochastic and
+    unseeded in the reference; parity runs use dropout=0)."""
+    gnn = getattr(model, "gnn", model)                                  # LocalUpdateGNN wrapper :230
+    sd = {k: v.detach().cpu().float() for k, v in gnn.state_dict().items()}
+    x = data.x.detach().cpu().float()
+    ei = data.edge_index.detach().cpu()
+    ea = getattr(data, "edge_attr", None)
+    ea = ea.detach().cpu().float() if ea is not None else None
+    return forward_from_state(sd, (gnn.n_layers, gnn.residual, gnn.edge_dim), x, ei, ea, training)
+
+
+def reference_gradients(model, data, loss_fn):
+    """Reference gradients by torch autograd through the restatement (train-mode BatchNorm, no
+    dropout).  loss_fn(embeddings) -> scalar.  Returns (embeddings, {state-dict key: grad}, grad_x)."""
+    gnn = getattr(model, "gnn", model)
+    sd = {}
+    for k, v in gnn.state_dict().items():
+        t = v.detach().cpu().float().clone()
+        if v.dtype.is_floating_point and "running_" not in k:
+            t.requires_grad_(True)
+        sd[k] = t
+    for l in range(gnn.n_layers):                       # lin_dst aliases lin_src (one parameter)
+        sd[f"convs.{l}.lin_dst.weight"] = sd[f"convs.{l}.lin_src.weight"]
+    x = data.x.detach().cpu().float().clone().requires_grad_(True)
+    ei = data.edge_index.detach().cpu()
+    ea = getattr(data, "edge_attr", None)
+    ea = ea.detach().cpu().float() if ea is not None else None
+    emb = forward_from_state(sd, (gnn.n_layers, gnn.residual, gnn.edge_dim), x, ei, ea, training=True)
+    loss = loss_fn(emb)
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if v.requires_grad and "lin_dst" not in k and v.grad is not None}
+    return emb.detach(), grads, x.grad, loss.detach()
+
+
+def triplet_loss_reference(emb, ia, ip, in_, margin):
+    """src/gnn/trainer.py:62-68"""
+    a, p, n = emb[ia], emb[ip], emb[in_]
+    pos = torch.sum((a - p) ** 2, dim=1)
+    neg = torch.sum((a - n) ** 2, dim=1)
+    return torch.relu(pos - neg + margin).mean()
 
 
 def randomize_bn_stats(model, seed=1):

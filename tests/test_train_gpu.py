@@ -1,0 +1,146 @@
+"""Training step on the GPU (BASELINE configs[4]) against torch autograd through the CPU restatement.
+Dropout is off for parity (the reference never seeds its RNG); a separate test covers dropout > 0."""
+import numpy as np
+import pytest
+import torch
+
+import gat_oracle as go
+from neural_spectral_codec_amd.gnn.model import create_spectral_gnn
+from neural_spectral_codec_amd.gnn.trainer import TripletLoss, GNNTrainer
+from neural_spectral_codec_amd.keyframe import graph_manager as gm
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _setup(n, edge_dim=2, dropout=0.0, seed=0):
+    torch.manual_seed(seed)
+    m = create_spectral_gnn(edge_dim=edge_dim, dropout=dropout)
+    go.randomize_bn_stats(m, seed + 1)
+    with torch.no_grad():
+        for c in m.gnn.convs:
+            c.bias.normal_(0, 0.1)
+    m = m.to("cuda")
+    g = gm.synthetic_chain_graph(n, device="cuda", seed=seed + 2)
+    rng = np.random.default_rng(seed)
+    trip = np.stack([rng.integers(0, n, 256), rng.integers(0, n, 256), rng.integers(0, n, 256)], 1)
+    return m, g, trip
+
+
+def _key_map(gnn):
+    keys = ["input_proj.weight", "input_proj.bias", "input_norm.weight", "input_norm.bias",
+            "output_proj.weight", "output_proj.bias"]
+    for l, conv in enumerate(gnn.convs):
+        keys += [f"convs.{l}.lin_src.weight", f"convs.{l}.att_src", f"convs.{l}.att_dst"]
+        if conv.lin_edge is not None:
+            keys += [f"convs.{l}.lin_edge.weight", f"convs.{l}.att_edge"]
+        keys += [f"convs.{l}.bias", f"batch_norms.{l}.weight", f"batch_norms.{l}.bias"]
+    return keys
+
+
+@pytest.mark.parametrize("n,edge_dim", [(40, 2), (300, 2), (300, None), (1500, 2)])
+def test_forward_train_and_gradients(n, edge_dim):
+    m, g, trip = _setup(n, edge_dim)
+    ref_model_state = {k: v.clone() for k, v in m.state_dict().items()}
+    crit = TripletLoss(margin=0.1)
+    tt = torch.from_numpy(trip)
+
+    # triplet loss + a random linear probe (the triplet gradient alone sums to zero over the rows,
+    # which would leave output_proj.bias untested)
+    R = torch.randn(n, 800, generator=torch.Generator().manual_seed(9)) * 1e-3
+    emb_ref, grads_ref, gx_ref, loss_ref = go.reference_gradients(
+        m, g, lambda e: go.triplet_loss_reference(e, tt[:, 0], tt[:, 1], tt[:, 2], 0.1) + (e * R).sum())
+
+    m.train()
+    g.x.requires_grad_(True)
+    emb = m(g)
+    loss = crit.forward_indexed(emb, trip[:, 0], trip[:, 1], trip[:, 2]) + (emb * R.cuda()).sum()
+    loss.backward()
+    assert _rel(emb.detach().cpu(), emb_ref) < 1e-4
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 1e-6
+    params = dict(m.gnn.named_parameters())
+    gscale = max(v.abs().max().item() for v in grads_ref.values())
+    for k in _key_map(m.gnn):
+        got = params[k].grad.detach().cpu().reshape(grads_ref[k].shape)
+        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
+            # a bias in front of a batch-statistics BatchNorm has an exactly-zero gradient: both sides
+            # hold only float32 rounding noise
+            assert got.abs().max().item() < 1e-3 * gscale and grads_ref[k].abs().max().item() < 1e-3 * gscale, k
+            continue
+        assert _rel(got, grads_ref[k]) < 2e-3, k            # float32 sums over n nodes, different order
+    assert _rel(g.x.grad.cpu(), gx_ref) < 2e-3
+    # BatchNorm running statistics moved like nn.BatchNorm1d (momentum 0.1, unbiased variance)
+    with torch.no_grad():
+        x = g.x.detach().cpu()
+        z = x @ ref_model_state["gnn.input_proj.weight"].cpu().t() + ref_model_state["gnn.input_proj.bias"].cpu()
+        rm = 0.9 * ref_model_state["gnn.input_norm.running_mean"].cpu() + 0.1 * z.mean(0)
+        rv = 0.9 * ref_model_state["gnn.input_norm.running_var"].cpu() + 0.1 * z.var(0, unbiased=True)
+    assert torch.allclose(m.gnn.input_norm.running_mean.cpu(), rm, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(m.gnn.input_norm.running_var.cpu(), rv, rtol=1e-4, atol=1e-5)
+    assert int(m.gnn.input_norm.num_batches_tracked) == 1
+
+
+def test_triplet_loss_matches_torch():
+    torch.manual_seed(0)
+    emb = torch.randn(500, 800, device="cuda", requires_grad=True)
+    rng = np.random.default_rng(1)
+    ia, ip, in_ = (rng.integers(0, 500, 1024) for _ in range(3))
+    crit = TripletLoss(0.1)
+    loss = crit.forward_indexed(emb, ia, ip, in_, scale=0.25)
+    loss.backward()
+    e2 = emb.detach().cpu().clone().requires_grad_(True)
+    ref = go.triplet_loss_reference(e2, torch.from_numpy(ia), torch.from_numpy(ip), torch.from_numpy(in_), 0.1) * 0.25
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert _rel(emb.grad.cpu(), e2.grad) < 1e-4
+    # reference call signature: three gathered tensors
+    l2 = crit(emb[ia], emb[ip], emb[in_])
+    assert abs(l2.item() - ref.item() * 4) < 1e-3 * abs(ref.item() * 4)
+
+
+def test_train_steps_reduce_loss_and_match_cpu_adam():
+    m, g, trip = _setup(400, 2)
+    import copy
+    cpu_model = copy.deepcopy(m).cpu()
+    tr = GNNTrainer(m, device="cuda", learning_rate=5e-4, weight_decay=1e-5, margin=0.1,
+                    batch_size=256, accumulation_steps=1)
+    losses = [tr.train_batches(g, trip) for _ in range(8)]
+    assert losses[-1] < losses[0]
+    # one step on the CPU with torch autograd through the restatement gives the same update
+    m2, g2, trip2 = _setup(400, 2)
+    tr2 = GNNTrainer(m2, device="cuda", batch_size=256, accumulation_steps=1)
+    tr2.train_batches(g2, trip2)
+    tt = torch.from_numpy(trip2)
+    _, grads_ref, _, _ = go.reference_gradients(
+        cpu_model, g2, lambda e: go.triplet_loss_reference(e, tt[:, 0], tt[:, 1], tt[:, 2], 0.1))
+    params = dict(cpu_model.gnn.named_parameters())
+    opt = torch.optim.Adam(cpu_model.parameters(), lr=5e-4, weight_decay=1e-5)
+    for k, gr in grads_ref.items():
+        params[k].grad = gr.reshape(params[k].shape)
+    opt.step()
+    got = dict(m2.gnn.named_parameters())
+    for k in ("output_proj.weight", "convs.1.lin_src.weight", "input_proj.weight"):
+        assert torch.allclose(got[k].detach().cpu(), params[k].detach(), rtol=1e-3, atol=2e-5), k
+
+
+def test_dropout_masks():
+    m, g, trip = _setup(600, 2, dropout=0.3)
+    m.train()
+    torch.manual_seed(5)
+    a = m(g)
+    torch.manual_seed(5)
+    b = m(g)
+    c = m(g)
+    assert torch.equal(a, b)                   # same torch seed -> same counter-based masks
+    assert not torch.equal(a, c)
+    loss = TripletLoss()(a[trip[:, 0]], a[trip[:, 1]], a[trip[:, 2]])
+    loss.backward()
+    for p in m.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    m.eval()
+    with torch.no_grad():
+        e = m(g)
+    assert torch.isfinite(e).all()

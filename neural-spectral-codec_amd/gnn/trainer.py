@@ -87,15 +87,23 @@ class GNNTrainer:
         n_batches = (len(triplets) + self.batch_size - 1) // self.batch_size
         losses = []
         self.optimizer.zero_grad()
+        from .. import distributed as nd
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
         for b in range(n_batches):
             bt = triplets[b * self.batch_size:(b + 1) * self.batch_size]
+            # data parallel over ranks: the graph forward is replicated, each rank takes a slice of the
+            # triplet batch; weighting by slice size makes the summed gradients those of the global mean
+            bt, weight = nd.split_triplets(bt, rank, world) if world > 1 else (bt, 1.0)
             embeddings = self.model(graph)                                                    # :205
             loss = self.criterion.forward_indexed(embeddings, bt[:, 0], bt[:, 1], bt[:, 2],
-                                                  scale=1.0 / self.accumulation_steps)        # :207-212
+                                                  scale=weight / self.accumulation_steps)     # :207-212
             loss.backward()                                                                   # :213
             losses.append(loss.detach())
             self.global_step += 1
             if (b + 1) % self.accumulation_steps == 0 or (b + 1) == n_batches:                # :219-221
+                nd.all_reduce_gradients(list(self.model.parameters()))     # one 2.46 MB RCCL all-reduce
                 self.optimizer.step()
                 self.optimizer.zero_grad()
         if not losses:

@@ -99,3 +99,44 @@ def test_shard_ranges_and_halo():
     # single process: all_gather is the identity
     t = torch.rand(5, 800)
     assert nd.all_gather_descriptors(t) is t
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)),
+              torch.nn.Parameter(torch.zeros(2, 2))]
+        ps[0].grad = torch.full((3, 5), float(rank + 1))
+        ps[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+        # ps[2] has no grad: skipped consistently on every rank
+        nd.all_reduce_gradients(ps)
+        trip = np.arange(30).reshape(10, 3)
+        part, wgt = nd.split_triplets(trip, rank, world)
+        q.put((rank, ps[0].grad.clone(), ps[1].grad.clone(), part, wgt))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_and_triplet_split():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, wsum = [], 0.0
+    for rank, g0, g1, part, wgt in res:
+        assert torch.equal(g0, torch.full((3, 5), 3.0))                 # 1 + 2
+        assert torch.equal(g1, torch.arange(7, dtype=torch.float32) * 3)
+        rows.append(part)
+        wsum += wgt
+    assert np.array_equal(np.concatenate(rows), np.arange(30).reshape(10, 3))
+    assert abs(wsum - 1.0) < 1e-12

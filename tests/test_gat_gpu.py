@@ -121,10 +121,3 @@ def test_other_dims_and_residual_proj():
         out = m(g)
     assert out.shape == (70, 32)
     assert _relerr(out.cpu(), go.forward_reference(m, g)) < RTOL
-
-
-def test_train_mode_is_refused_not_faked():
-    m = _model().train()
-    g = gm.synthetic_chain_graph(10, device="cuda")
-    with pytest.raises(NotImplementedError):
-        m(g)

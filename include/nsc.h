@@ -216,6 +216,26 @@ int    nsc_triplet_loss(const float *emb, const int64_t *anchors, const int64_t 
                         float margin, float scale, float *loss, float *grad_emb, void *ws, size_t ws_bytes,
                         void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Stage-1 retrieval: 1-D Wasserstein distance = L1 of CDFs, top-k.
+ * Replaces wasserstein_distance_batch_torch / _matrix_torch (reference src/retrieval/wasserstein.py
+ * :134-172, :232-273), WassersteinRetriever.query (:328-384) and the spatial filter of
+ * TwoStageRetrieval._global_retrieval (src/retrieval/two_stage_retrieval.py:145-202).
+ * ------------------------------------------------------------------------------------------ */
+/* cdf[i] = cumsum(normalised hists[i]);  divide_plain = 1: h / sum (query form, wasserstein.py:153-155),
+ * 0: h / (sum + eps) (database / matrix form, :158-163); rows with sum <= eps stay unnormalised. */
+int nsc_w1_cdf(const float *hists, int32_t n, int32_t dim, float eps, int32_t divide_plain, float *cdf,
+               void *stream);
+/* dist (Q, N): W1 of every query CDF against every database row (raw histograms, normalised on the
+ * fly).  db_pos (N,3) / q_pos (Q,3) nullable: pairs closer than min_dist get +inf (spatial filter). */
+int nsc_w1_distances(const float *db, int32_t N, int32_t dim, float eps, const float *q_cdf, int32_t Q,
+                     const float *db_pos, const float *q_pos, float min_dist, float *dist, void *stream);
+/* idx/val (Q, k): the k smallest entries of each row of dist, ascending, ties to the smaller index
+ * (k <= 256 and ceil(N/2048)*k <= 4096). */
+size_t nsc_topk_workspace_bytes(int32_t Q, int32_t N, int32_t k);
+int nsc_topk_smallest(const float *dist, int32_t Q, int32_t N, int32_t k, int64_t *idx, float *val,
+                      void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

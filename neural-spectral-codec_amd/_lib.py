@@ -99,6 +99,10 @@ SYMBOLS = {
                                         _vp, _vp, _sz, _vp]),
     "nsc_gat_backward": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, C.POINTER(GatTrainCfg), _vp,
                                    C.POINTER(GatGrads), _vp, _sz, _vp]),
+    "nsc_w1_cdf": (C.c_int, [_vp, _i32, _i32, C.c_float, _i32, _vp, _vp]),
+    "nsc_w1_distances": (C.c_int, [_vp, _i32, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, _vp, _vp]),
+    "nsc_topk_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "nsc_topk_smallest": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "nsc_triplet_workspace_bytes": (_sz, [_i32]),
     "nsc_triplet_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, C.c_float, _vp, _vp, _vp,
                                    _sz, _vp]),

@@ -1,0 +1,262 @@
+// nsc_retrieval.hip -- stage-1 Wasserstein retrieval on gfx950 ("next" row 1).
+//
+// Path (reference file:line):
+//   wasserstein_distance_batch_torch      src/retrieval/wasserstein.py:134-172  (query vs database)
+//   wasserstein_distance_matrix_torch     src/retrieval/wasserstein.py:232-273  (many queries)
+//   WassersteinRetriever.query            src/retrieval/wasserstein.py:328-384  (top-k smallest)
+//   TwoStageRetrieval._global_retrieval   src/retrieval/two_stage_retrieval.py:145-202 (spatial filter)
+//
+// 1-D W1 between histograms = L1 distance of their CDFs.  One wavefront per database row: the row is
+// streamed once from HBM (3 200 B for 800 bins), normalised and prefix-summed in registers (16 bins per
+// lane + a wave scan of the lane totals), and compared with every query CDF of the batch.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "../../include/nsc.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sumf(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// inclusive CDF of one row held as PER consecutive bins per lane; returns the row sum
+template <int PER>
+__device__ __forceinline__ float row_cdf(float (&v)[PER], int lane, float eps, int divide_plain)
+{
+    float tot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tot += v[k];
+    const float sum = wave_sumf(tot);
+    // wasserstein.py:153-163: query / sum (if sum > eps); database row / (sum + eps) (if sum > eps)
+    float scale = 1.0f;
+    if (sum > eps) scale = divide_plain ? sum : sum + eps;
+    float run = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { v[k] = (sum > eps) ? v[k] / scale : v[k]; run += v[k]; v[k] = run; }
+    // exclusive scan of the lane totals (Hillis-Steele over 64 lanes)
+    float inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    const float off = inc - run;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] += off;
+    return sum;
+}
+
+template <int PER>
+__device__ __forceinline__ void load_row(const float *__restrict__ row, int D, int lane, float (&v)[PER])
+{
+#pragma unroll
+    for (int k = 0; k < PER; k += 4) {
+        const int c = lane * PER + k;
+        if (c + 3 < D) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(row + c);
+            v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[k + j] = (c + j < D) ? row[c + j] : 0.0f;
+        }
+    }
+}
+
+// CDFs of the queries (wave per query), written to global for the distance kernel
+template <int PER>
+__global__ __launch_bounds__(256) void w1_cdf_kernel(const float *__restrict__ h, int n, int D, float eps,
+                                                     int divide_plain, float *__restrict__ cdf)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float v[PER];
+    load_row<PER>(h + (long long)i * D, D, lane, v);
+    row_cdf<PER>(v, lane, eps, divide_plain);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = lane * PER + k;
+        if (c < D) cdf[(long long)i * D + c] = v[k];
+    }
+}
+
+// dist[q][i] = sum_k |cdf_db[i][k] - cdf_q[q][k]|, +inf where the spatial filter excludes the pair
+template <int PER>
+__global__ __launch_bounds__(256) void w1_dist_kernel(const float *__restrict__ db, int N, int D, float eps,
+                                                      const float *__restrict__ qcdf, int Q,
+                                                      const float *__restrict__ db_pos,
+                                                      const float *__restrict__ q_pos, float min_dist,
+                                                      float *__restrict__ dist)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    float v[PER];
+    load_row<PER>(db + (long long)i * D, D, lane, v);
+    row_cdf<PER>(v, lane, eps, 0);
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (db_pos) { px = db_pos[i * 3]; py = db_pos[i * 3 + 1]; pz = db_pos[i * 3 + 2]; }
+    for (int q = 0; q < Q; ++q) {
+        float w[PER];
+        load_row<PER>(qcdf + (long long)q * D, D, lane, w);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = lane * PER + k;
+            if (c < D) s += fabsf(v[k] - w[k]);
+        }
+        s = wave_sumf(s);
+        if (db_pos && q_pos) {       // two_stage_retrieval.py:160-170: skip database frames that are too close
+            const float dx = px - q_pos[q * 3], dy = py - q_pos[q * 3 + 1], dz = pz - q_pos[q * 3 + 2];
+            if (sqrtf(dx * dx + dy * dy + dz * dz) < min_dist) s = INFINITY;
+        }
+        if (lane == 0) dist[(long long)q * N + i] = s;
+    }
+}
+
+// k smallest of each row of dist, ascending, ties to the smaller index.  Two stages:
+//   stage 1: grid (chunks, Q): a workgroup keeps its chunk of 2 048 distances in registers (8 per
+//            thread) and extracts the chunk's k smallest by k rounds of (thread-local min, LDS reduce);
+//   stage 2: one workgroup per query merges the chunks' candidates the same way.
+// Picks are ordered by (value, index), so the result does not depend on the chunking.
+constexpr int TK_CHUNK = 2048, TK_PER = 8;
+
+__device__ __forceinline__ bool lex_less(float v, int i, float w, int j) { return v < w || (v == w && i < j); }
+
+template <int PERT>
+__device__ __forceinline__ void select_k(float (&v)[PERT], int (&id)[PERT], int k, float *sv, int *si,
+                                         float *out_v, int *out_i)
+{
+    const int tid = threadIdx.x;
+    for (int r = 0; r < k; ++r) {
+        float bv = INFINITY; int bi = 0x7fffffff, bs = -1;
+#pragma unroll
+        for (int u = 0; u < PERT; ++u)
+            if (lex_less(v[u], id[u], bv, bi)) { bv = v[u]; bi = id[u]; bs = u; }
+        sv[tid] = bv; si[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o && lex_less(sv[tid + o], si[tid + o], sv[tid], si[tid])) { sv[tid] = sv[tid + o]; si[tid] = si[tid + o]; }
+            __syncthreads();
+        }
+        const float wv = sv[0]; const int wi = si[0];
+        if (tid == 0) { out_v[r] = wv; out_i[r] = wi; }
+        if (bs >= 0 && bi == wi && bv == wv) {              // the winning thread retires its element
+#pragma unroll
+            for (int u = 0; u < PERT; ++u) if (u == bs) { v[u] = INFINITY; id[u] = 0x7fffffff; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_stage1_kernel(const float *__restrict__ dist, int N, int k,
+                                                          float *__restrict__ cand_v, int *__restrict__ cand_i)
+{
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int q = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const float *d = dist + (long long)q * N;
+    float v[TK_PER]; int id[TK_PER];
+#pragma unroll
+    for (int u = 0; u < TK_PER; ++u) {
+        const int i = chunk * TK_CHUNK + u * 256 + tid;
+        v[u] = (i < N) ? d[i] : INFINITY;
+        id[u] = (i < N) ? i : 0x7fffffff;
+    }
+    const long long base = ((long long)q * gridDim.x + chunk) * k;
+    select_k<TK_PER>(v, id, k, sv, si, cand_v + base, cand_i + base);
+}
+
+__global__ __launch_bounds__(256) void topk_stage2_kernel(const float *__restrict__ cand_v, const int *__restrict__ cand_i,
+                                                          int ncand, int k, long long *__restrict__ idx_out,
+                                                          float *__restrict__ val_out)
+{
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ float ov[256];
+    __shared__ int oi[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    constexpr int PERT = 16;                                  // up to 4 096 candidates per query
+    float v[PERT]; int id[PERT];
+#pragma unroll
+    for (int u = 0; u < PERT; ++u) {
+        const int c = u * 256 + tid;
+        v[u] = (c < ncand) ? cand_v[(long long)q * ncand + c] : INFINITY;
+        id[u] = (c < ncand) ? cand_i[(long long)q * ncand + c] : 0x7fffffff;
+    }
+    select_k<PERT>(v, id, k, sv, si, ov, oi);
+    if (tid < k) {
+        idx_out[(long long)q * k + tid] = (oi[tid] == 0x7fffffff) ? -1 : oi[tid];
+        val_out[(long long)q * k + tid] = ov[tid];
+    }
+}
+
+int per_of(int D) { int p = ((D + 63) / 64 + 3) / 4 * 4; return p < 4 ? 4 : p; }
+
+}  // namespace
+
+extern "C" {
+
+int nsc_w1_cdf(const float *hists, int32_t n, int32_t D, float eps, int32_t divide_plain, float *cdf, void *stream_)
+{
+    if (n < 0 || D < 1 || D > 1024) return NSC_EUNSUPPORTED;
+    if (n == 0) return NSC_OK;
+    if (!hists || !cdf) return NSC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const dim3 grid((n + 3) / 4), block(256);
+    switch (per_of(D)) {
+    case 4: hipLaunchKernelGGL(w1_cdf_kernel<4>, grid, block, 0, st, hists, n, D, eps, divide_plain, cdf); break;
+    case 8: hipLaunchKernelGGL(w1_cdf_kernel<8>, grid, block, 0, st, hists, n, D, eps, divide_plain, cdf); break;
+    case 12: hipLaunchKernelGGL(w1_cdf_kernel<12>, grid, block, 0, st, hists, n, D, eps, divide_plain, cdf); break;
+    default: hipLaunchKernelGGL(w1_cdf_kernel<16>, grid, block, 0, st, hists, n, D, eps, divide_plain, cdf); break;
+    }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_w1_distances(const float *db, int32_t N, int32_t D, float eps, const float *q_cdf, int32_t Q,
+                     const float *db_pos, const float *q_pos, float min_dist, float *dist, void *stream_)
+{
+    if (N < 0 || Q < 0 || D < 1 || D > 1024) return NSC_EUNSUPPORTED;
+    if (N == 0 || Q == 0) return NSC_OK;
+    if (!db || !q_cdf || !dist) return NSC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const dim3 grid((N + 3) / 4), block(256);
+    switch (per_of(D)) {
+    case 4: hipLaunchKernelGGL(w1_dist_kernel<4>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
+    case 8: hipLaunchKernelGGL(w1_dist_kernel<8>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
+    case 12: hipLaunchKernelGGL(w1_dist_kernel<12>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
+    default: hipLaunchKernelGGL(w1_dist_kernel<16>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
+    }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+size_t nsc_topk_workspace_bytes(int32_t Q, int32_t N, int32_t k)
+{
+    if (Q <= 0 || N <= 0 || k <= 0) return 0;
+    const size_t chunks = ((size_t)N + TK_CHUNK - 1) / TK_CHUNK;
+    return (size_t)Q * chunks * k * 8;
+}
+
+int nsc_topk_smallest(const float *dist, int32_t Q, int32_t N, int32_t k, int64_t *idx, float *val, void *ws,
+                      size_t ws_bytes, void *stream_)
+{
+    if (Q < 0 || N < 0 || k < 0 || k > N) return NSC_EINVAL;
+    if (Q == 0 || k == 0) return NSC_OK;
+    if (!dist || !idx || !val) return NSC_EINVAL;
+    const int chunks = (N + TK_CHUNK - 1) / TK_CHUNK;
+    if (k > 256 || (long long)chunks * k > 4096) return NSC_EUNSUPPORTED;   // N*k <= 8.4 M entries
+    if (!ws || ws_bytes < nsc_topk_workspace_bytes(Q, N, k)) return NSC_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    float *cv = static_cast<float *>(ws);
+    int *ci = reinterpret_cast<int *>(cv + (size_t)Q * chunks * k);
+    hipLaunchKernelGGL(topk_stage1_kernel, dim3(chunks, Q), dim3(256), 0, st, dist, N, k, cv, ci);
+    hipLaunchKernelGGL(topk_stage2_kernel, dim3(Q), dim3(256), 0, st, cv, ci, chunks * k, k,
+                       reinterpret_cast<long long *>(idx), val);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,5 @@
+"""Mirror of the reference's ``retrieval`` package for stage-1 (Wasserstein) retrieval."""
+from .wasserstein import (WassersteinRetriever, wasserstein_distance_batch_torch,
+                          wasserstein_distance_matrix_torch)
+
+__all__ = ["WassersteinRetriever", "wasserstein_distance_batch_torch", "wasserstein_distance_matrix_torch"]

@@ -1,0 +1,146 @@
+"""1-D Wasserstein retrieval on MI355X -- drop-in for the device-side functions of the reference's
+src/retrieval/wasserstein.py: ``wasserstein_distance_batch_torch`` (:134-172),
+``wasserstein_distance_matrix_torch`` (:232-273) and ``WassersteinRetriever`` (:276-389).
+
+W1 between 1-D histograms is the L1 distance of their CDFs.  The database is streamed once per query
+batch by nsc_w1_distances (one wavefront per row), the k smallest distances are selected on the device
+(nsc_topk_smallest).  Additive over the reference: batched queries, the spatial filter of
+TwoStageRetrieval._global_retrieval (two_stage_retrieval.py:160-170) fused into the distance kernel, and
+an amortised-doubling database buffer instead of torch.cat per insert (:324).
+"""
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _dev_f32(t, device=None):
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    t = t.detach().to(dtype=torch.float32)
+    if device is not None:
+        t = t.to(device)
+    _lib.require_cuda(t, "histograms")
+    return t.contiguous()
+
+
+def _cdf(h: torch.Tensor, eps: float, divide_plain: bool) -> torch.Tensor:
+    out = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        st = _lib.lib().nsc_w1_cdf(_lib.ptr(h), int(h.shape[0]), int(h.shape[1]), float(eps),
+                                   int(divide_plain), _lib.ptr(out), _lib.stream_ptr(h.device))
+    _lib.check(st, "nsc_w1_cdf")
+    return out
+
+
+def _distances(db: torch.Tensor, qcdf: torch.Tensor, eps: float, db_pos=None, q_pos=None,
+               min_dist: float = 0.0) -> torch.Tensor:
+    n, d, q = int(db.shape[0]), int(db.shape[1]), int(qcdf.shape[0])
+    dist = torch.empty((q, n), dtype=torch.float32, device=db.device)
+    with torch.cuda.device(db.device):
+        st = _lib.lib().nsc_w1_distances(_lib.ptr(db), n, d, float(eps), _lib.ptr(qcdf), q,
+                                         _lib.ptr(db_pos), _lib.ptr(q_pos), float(min_dist),
+                                         _lib.ptr(dist), _lib.stream_ptr(db.device))
+    _lib.check(st, "nsc_w1_distances")
+    return dist
+
+
+def _topk(dist: torch.Tensor, k: int):
+    q, n = int(dist.shape[0]), int(dist.shape[1])
+    idx = torch.empty((q, k), dtype=torch.int64, device=dist.device)
+    val = torch.empty((q, k), dtype=torch.float32, device=dist.device)
+    L = _lib.lib()
+    nbytes = L.nsc_topk_workspace_bytes(q, n, k)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dist.device)
+    with torch.cuda.device(dist.device):
+        st = L.nsc_topk_smallest(_lib.ptr(dist), q, n, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(ws), nbytes,
+                                 _lib.stream_ptr(dist.device))
+    _lib.check(st, "nsc_topk_smallest")
+    return idx, val
+
+
+def wasserstein_distance_batch_torch(query_hist: torch.Tensor, database_hists: torch.Tensor,
+                                     epsilon: float = 1e-8) -> torch.Tensor:
+    """(n_bins,) query vs (n_database, n_bins) -> (n_database,)          wasserstein.py:134-172"""
+    db = _dev_f32(database_hists)
+    q = _dev_f32(query_hist, db.device).reshape(1, -1)
+    return _distances(db, _cdf(q, epsilon, True), epsilon)[0]
+
+
+def wasserstein_distance_matrix_torch(hists1: torch.Tensor, hists2: Optional[torch.Tensor] = None,
+                                      epsilon: float = 1e-8) -> torch.Tensor:
+    """(n1, n_bins) x (n2, n_bins) -> (n1, n2), D[i,j] = W1(hists1[i], hists2[j])   wasserstein.py:232-273"""
+    h1 = _dev_f32(hists1)
+    h2 = h1 if hists2 is None else _dev_f32(hists2, h1.device)
+    return _distances(h2, _cdf(h1, epsilon, False), epsilon)
+
+
+class WassersteinRetriever:
+    """wasserstein.py:276-389 (``use_torch`` is accepted for signature compatibility; the database
+    always lives in HBM)."""
+
+    def __init__(self, use_torch: bool = True, device: str = 'cuda'):
+        self.use_torch = use_torch
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NscError("WassersteinRetriever keeps its database in HBM: device must be a HIP device")
+        self._buf = None
+        self._pos = None
+        self.database_size = 0
+
+    @property
+    def database_hists(self):
+        return None if self._buf is None else self._buf[:self.database_size]
+
+    def add_to_database(self, histograms: Union[np.ndarray, torch.Tensor], positions=None):
+        """:301-326.  ``positions`` (n,3) are optional keyframe translations for the spatial filter."""
+        h = _dev_f32(histograms if not isinstance(histograms, np.ndarray) else torch.from_numpy(histograms),
+                     self.device)
+        if h.dim() == 1:
+            h = h.unsqueeze(0)
+        n, d = int(h.shape[0]), int(h.shape[1])
+        need = self.database_size + n
+        if self._buf is None or need > self._buf.shape[0]:
+            cap = max(need, 2 * (0 if self._buf is None else self._buf.shape[0]), 1024)
+            nb = torch.empty((cap, d), dtype=torch.float32, device=self.device)
+            npos = torch.zeros((cap, 3), dtype=torch.float32, device=self.device)
+            if self._buf is not None:
+                nb[:self.database_size] = self._buf[:self.database_size]
+                npos[:self.database_size] = self._pos[:self.database_size]
+            self._buf, self._pos = nb, npos
+        self._buf[self.database_size:need] = h
+        if positions is not None:
+            self._pos[self.database_size:need] = torch.as_tensor(np.asarray(positions), dtype=torch.float32).to(self.device)
+        self.database_size = need
+
+    def query_batch(self, query_hists, top_k: int = 10, query_positions=None, min_distance: float = 0.0):
+        """(Q, n_bins) queries -> (indices (Q,k) int64, distances (Q,k)) device tensors, ascending.
+        With ``query_positions`` database entries closer than ``min_distance`` are excluded
+        (two_stage_retrieval.py:160-170)."""
+        if self.database_size == 0:
+            e = torch.empty((0, 0), device=self.device)
+            return e.long(), e
+        q = _dev_f32(query_hists, self.device)
+        if q.dim() == 1:
+            q = q.unsqueeze(0)
+        db = self._buf[:self.database_size]
+        qp = dbp = None
+        if query_positions is not None:
+            qp = torch.as_tensor(np.asarray(query_positions), dtype=torch.float32).to(self.device).reshape(-1, 3).contiguous()
+            dbp = self._pos[:self.database_size]
+        dist = _distances(db, _cdf(q, 1e-8, True), 1e-8, dbp, qp, min_distance)
+        return _topk(dist, min(top_k, self.database_size))
+
+    def query(self, query_hist: Union[np.ndarray, torch.Tensor], top_k: int = 10) -> tuple:
+        """:328-384: (indices (top_k,), distances (top_k,)) as numpy arrays, ascending distance."""
+        if self.database_size == 0:
+            return np.array([]), np.array([])
+        idx, val = self.query_batch(query_hist, top_k)
+        return idx[0].cpu().numpy(), val[0].cpu().numpy()
+
+    def clear_database(self):
+        """:386-389"""
+        self._buf = self._pos = None
+        self.database_size = 0

@@ -1,0 +1,39 @@
+"""CPU restatement (numpy, float32) of the reference's stage-1 Wasserstein retrieval.
+
+TEST INFRASTRUCTURE ONLY.  Parity status: PINNED against outputs of the reference itself
+(src/retrieval/wasserstein.py imported by oracle/gen_golden_retrieval.py; tests/golden/wasserstein.npz).
+"""
+import numpy as np
+
+
+def batch(query, database, eps=1e-8):
+    """wasserstein_distance_batch_torch, wasserstein.py:134-172 (float32 throughout)."""
+    q = np.asarray(query, np.float32)
+    db = np.asarray(database, np.float32)
+    qs = q.sum(dtype=np.float32)
+    if qs > eps:
+        q = q / qs                                            # :153-155 (no epsilon in the denominator)
+    ds = db.sum(axis=1, keepdims=True, dtype=np.float32)
+    db = np.where(ds > eps, db / (ds + np.float32(eps)), db)  # :158-163
+    qc = np.cumsum(q, dtype=np.float32)
+    dc = np.cumsum(db, axis=1, dtype=np.float32)
+    return np.abs(dc - qc[None, :]).sum(axis=1, dtype=np.float32)      # :170
+
+
+def matrix(h1, h2=None, eps=1e-8):
+    """wasserstein_distance_matrix_torch, wasserstein.py:232-273."""
+    h1 = np.asarray(h1, np.float32)
+    h2 = h1 if h2 is None else np.asarray(h2, np.float32)
+
+    def norm(h):
+        s = h.sum(axis=1, keepdims=True, dtype=np.float32)
+        return np.where(s > eps, h / (s + np.float32(eps)), h)
+    c1 = np.cumsum(norm(h1), axis=1, dtype=np.float32)
+    c2 = np.cumsum(norm(h2), axis=1, dtype=np.float32)
+    return np.abs(c1[:, None, :] - c2[None, :, :]).sum(axis=2, dtype=np.float32)
+
+
+def topk(dist, k):
+    """WassersteinRetriever.query, wasserstein.py:360-366: k smallest, ascending (ties: lower index)."""
+    order = np.lexsort((np.arange(len(dist)), dist))[:k]
+    return order, dist[order]

@@ -81,6 +81,17 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
                       const int32_t *lut, float *out_desc, float *out_raw, float *out_interp,
                       void *ws, size_t ws_bytes, void *stream);
 
+/* The two halves of nsc_encode_clouds as separate launches, so a caller can overlap the (ALU-bound)
+ * finish of batch k with the (HBM-bound) scatter of batch k+1 on two streams:
+ *   nsc_scatter_clouds: points -> (n_clouds, E, 360) uint32 images of the MINIMUM SQUARED range
+ *                       (float32 bit pattern, 0xffffffff = empty pixel)    range_image.py:129-208
+ *   nsc_finish_images : those images -> sqrt, interpolation, FFT, histogram, normalisation */
+int nsc_scatter_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_clouds,
+                       int64_t total_points, int32_t stride_floats, const NscEncParams *p,
+                       uint32_t *out_sqr, void *stream);
+int nsc_finish_images(const uint32_t *sqr, int32_t n_images, const NscEncParams *p, const int32_t *lut,
+                      float *out_desc, float *out_raw, float *out_interp, void *stream);
+
 /* SpectralEncoder.forward / encode_range_image for a batch of range images (no projection, no
  * interpolation; rows != target_rows are average-pooled like adaptive_avg_pool2d).
  *   imgs      (n_images, rows, 360) float32, rows 1..64
@@ -88,6 +99,11 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
 int nsc_encode_range_images(const float *imgs, int32_t n_images, int32_t rows,
                             const NscEncParams *p, const int32_t *lut, float *out_desc,
                             void *stream);
+
+/* interpolate_range_image(img, 'linear') (reference range_image.py:15-89) for a batch of float32 range
+ * images (n_images, rows, 360), 0 = empty pixel; rows 1..64. */
+int nsc_interpolate_range_images(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,
+                                 float *out, void *stream);
 
 /* Parity triage: per point, the pixel index row*360+col the scatter uses (-1 = dropped) and
  * whether the exact (float64 atan2) path decided it (bit0 azimuth, bit1 elevation). */

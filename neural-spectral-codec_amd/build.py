@@ -43,7 +43,10 @@ def build_hip(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + sources()
+    flags = list(HIPCC_FLAGS)
+    if os.environ.get("NSC_DEV_BUILD") == "1":       # enables the NSC_TUNE_* development knobs
+        flags.append("-DNSC_DEV_TUNING")
+    cmd = [hipcc] + flags + ["-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -384,6 +384,8 @@ __device__ __forceinline__ double wave_sum(double v)
 // everything after the image exists in LDS
 //   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
 //   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
+//   mode 2: img holds float32 range images from the caller -> interpolate + row copy only
+//           (interpolate_range_image(), range_image.py:15-89), result to out_interp
 // ---------------------------------------------------------------------------------------------
 // Twiddles and histogram segments -> LDS, by `nthr` cooperating threads (index t).  In the fused
 // kernel one wave does this while the others already stream points, so none of its global-load
@@ -410,6 +412,8 @@ __device__ __forceinline__ void setup_tables(unsigned char *lds, const EncDev &d
 // everything after the image exists in LDS
 //   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
 //   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
+//   mode 2: img holds float32 range images from the caller -> interpolate + row copy only
+//           (interpolate_range_image(), range_image.py:15-89), result to out_interp
 // ---------------------------------------------------------------------------------------------
 // Twiddles and histogram segments -> LDS.  Called at kernel start (before the point stream in the
 // fused kernel) so none of its global-load latency sits in the finish phase.  The LUT is monotone:
@@ -445,6 +449,8 @@ __device__ __forceinline__ void setup_tables(unsigned char *lds, const EncDev &d
 // everything after the image exists in LDS
 //   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
 //   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
+//   mode 2: img holds float32 range images from the caller -> interpolate + row copy only
+//           (interpolate_range_image(), range_image.py:15-89), result to out_interp
 template <int NW>
 __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d, int mode,
                                              float *__restrict__ out_desc,
@@ -463,7 +469,7 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
     int *rowflag = reinterpret_cast<int *>(lds + lp.misc + MAXR * 8);
     int *rowsrc = rowflag + MAXE;
 
-    if (mode == 0) {
+    if (mode == 0 || mode == 2) {
         // each wave converts and interpolates the rows it owns: no workgroup barrier in between
         for (int r = wave; r < E; r += NW) {
             float *row = img + r * A;
@@ -472,7 +478,7 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int c = lane + 64 * j;
-                if (c < A) {
+                if (c < A && mode == 0) {
                     const unsigned v = raw[c];
                     // min over sqrtf(s_i) == sqrtf(min s_i): sqrtf is correctly rounded, hence monotone
                     const float rr = (v == NSC_EMPTY_BITS) ? 0.0f : sqrtf(__uint_as_float(v));   // :162,:214
@@ -481,11 +487,11 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
                 }
             }
             wave_sync();
-            const int nv = interp_row(row, lane, d.interp != 0);
+            const int nv = interp_row(row, lane, d.interp != 0 || mode == 2);
             if (lane == 0) rowflag[r] = (nv > 0);
         }
         __syncthreads();
-        if (d.interp) {                                           // range_image.py:77-87
+        if (d.interp || mode == 2) {                              // range_image.py:77-87
             unsigned long long ne = 0ull;
             for (int r = 0; r < E; ++r) ne |= (unsigned long long)(rowflag[r] != 0) << r;
             const unsigned long long all = (E == 64) ? ~0ull : ((1ull << E) - 1ull);
@@ -513,6 +519,7 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
         if (out_interp)
             for (int r = wave; r < E; r += NW)                    // rows this wave owns (or just copied)
                 for (int c = lane; c < A; c += 64) out_interp[r * A + c] = img[r * A + c];
+        if (mode == 2) return;
     }
 
     float *rows = img;
@@ -634,16 +641,23 @@ __global__ __launch_bounds__(NW * 64) void scatter_split_kernel(
     if (a < b) scatter_range<NT, U>(pts, a, b, stride, tid, d.bp, img);
     __syncthreads();
     unsigned *g = ws + (long long)c * npix;
+    if (parts == 1) {                       // sole owner of the cloud: plain 16-byte stores, no pre-fill
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(img);
+        uint4 *g4 = reinterpret_cast<uint4 *>(g);
+        for (int i = tid; i < npix / 4; i += NT) g4[i] = s4[i];
+        return;
+    }
     for (int i = tid; i < npix; i += NT) {
         const unsigned v = img[i];
         if (v != NSC_EMPTY_BITS) atomicMin(&g[i], v);
     }
 }
 
-// src_u32 != null: squared-range workspace images (mode 0); else src_f32 caller images (mode 1)
+// src_u32 != null: squared-range workspace images (mode 0); else src_f32 caller images
+// (mode 1: descriptor only; interp_only: mode 2)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void finish_kernel(
-    const unsigned *__restrict__ src_u32, const float *__restrict__ src_f32, EncDev d,
+    const unsigned *__restrict__ src_u32, const float *__restrict__ src_f32, int interp_only, EncDev d,
     const int *__restrict__ lut, float *__restrict__ out_desc, float *__restrict__ out_raw,
     float *__restrict__ out_interp)
 {
@@ -674,7 +688,7 @@ __global__ __launch_bounds__(NW * 64) void finish_kernel(
     }
     __syncthreads();
     const long long D = (long long)d.R * d.B;
-    finish_image<NW>(lds, d, src_u32 ? 0 : 1, out_desc + c * D,
+    finish_image<NW>(lds, d, src_u32 ? 0 : (interp_only ? 2 : 1), out_desc ? out_desc + c * D : nullptr,
                      out_raw ? out_raw + (long long)c * npix : nullptr,
                      out_interp ? out_interp + (long long)c * npix : nullptr);
 }
@@ -701,10 +715,17 @@ constexpr int FUSED_U = 4;           // float4 loads in flight per thread (split
 constexpr int SPLIT_MIN_PTS = 16384; // a part must amortise its 5 760-pixel LDS init + flush
 constexpr int SPLIT_TARGET_WGS = 512;
 
+// Development knobs (tools/ab_enc.py, tools/sweep_enc.py) exist only in builds made with
+// NSC_DEV_BUILD=1 (-DNSC_DEV_TUNING); the shipped library reads no environment variables.
 int tune_env(const char *name, int def)
 {
-    const char *v = getenv(name);   // development knob; unset in production
+#ifdef NSC_DEV_TUNING
+    const char *v = getenv(name);
     return v ? atoi(v) : def;
+#else
+    (void)name;
+    return def;
+#endif
 }
 
 int check_params(const NscEncParams *p)
@@ -843,9 +864,55 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
         auto kf = finish_kernel<FUSED_NW>;
         if ((st = set_lds(kf, lp.total)) != NSC_OK) return st;
         hipLaunchKernelGGL(kf, dim3(n_clouds), dim3(FUSED_NW * 64), lp.total, stream,
-                           static_cast<const unsigned *>(ws), static_cast<const float *>(nullptr), d, lut,
+                           static_cast<const unsigned *>(ws), static_cast<const float *>(nullptr), 0, d, lut,
                            out_desc, out_raw, out_interp);
     }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_scatter_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_clouds, int64_t total_points,
+                       int32_t stride, const NscEncParams *p, uint32_t *out_sqr, void *stream_)
+{
+    int st = check_params(p);
+    if (st != NSC_OK) return st;
+    if (n_clouds < 0 || total_points < 0 || (stride != 3 && stride != 4)) return NSC_EINVAL;
+    if (n_clouds == 0) return NSC_OK;
+    if (!cloud_offsets || !out_sqr || (!pts && total_points > 0)) return NSC_EINVAL;
+    if (stride == 4 && (reinterpret_cast<uintptr_t>(pts) & 15u)) return NSC_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const EncDev d = make_dev(p, p->n_elevation);
+    const int parts = split_parts(n_clouds, total_points);
+    const long long *off = reinterpret_cast<const long long *>(cloud_offsets);
+    const int img_bytes = d.E * A * 4;
+    if (parts > 1) {
+        if (hipMemsetAsync(out_sqr, 0xff, (size_t)n_clouds * img_bytes, stream) != hipSuccess) return NSC_ELAUNCH;
+        auto ks = scatter_split_kernel<FUSED_NW, FUSED_U>;
+        if ((st = set_lds(ks, img_bytes)) != NSC_OK) return st;
+        hipLaunchKernelGGL(ks, dim3(n_clouds * parts), dim3(FUSED_NW * 64), img_bytes, stream, pts, off, stride, parts,
+                           d, out_sqr);
+    } else {
+        auto ks = scatter_split_kernel<4, 8>;          // one 4-wave workgroup per cloud, 23 KB LDS
+        if ((st = set_lds(ks, img_bytes)) != NSC_OK) return st;
+        hipLaunchKernelGGL(ks, dim3(n_clouds), dim3(256), img_bytes, stream, pts, off, stride, 1, d, out_sqr);
+    }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_finish_images(const uint32_t *sqr, int32_t n_images, const NscEncParams *p, const int32_t *lut,
+                      float *out_desc, float *out_raw, float *out_interp, void *stream_)
+{
+    int st = check_params(p);
+    if (st != NSC_OK) return st;
+    if (n_images < 0) return NSC_EINVAL;
+    if (n_images == 0) return NSC_OK;
+    if (!sqr || !lut || !out_desc) return NSC_EINVAL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const EncDev d = make_dev(p, p->n_elevation);
+    const LdsPlan lp = lds_plan(d.E, d.R, d.B, FUSED_NW);
+    auto kf = finish_kernel<FUSED_NW>;
+    if ((st = set_lds(kf, lp.total)) != NSC_OK) return st;
+    hipLaunchKernelGGL(kf, dim3(n_images), dim3(FUSED_NW * 64), lp.total, stream, sqr,
+                       static_cast<const float *>(nullptr), 0, d, lut, out_desc, out_raw, out_interp);
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 
@@ -864,8 +931,31 @@ int nsc_encode_range_images(const float *imgs, int32_t n_images, int32_t rows, c
     auto kf = finish_kernel<FUSED_NW>;
     if ((st = set_lds(kf, lp.total)) != NSC_OK) return st;
     hipLaunchKernelGGL(kf, dim3(n_images), dim3(FUSED_NW * 64), lp.total, stream,
-                       static_cast<const unsigned *>(nullptr), imgs, d, lut, out_desc,
+                       static_cast<const unsigned *>(nullptr), imgs, 0, d, lut, out_desc,
                        static_cast<float *>(nullptr), static_cast<float *>(nullptr));
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_interpolate_range_images(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,
+                                 float *out, void *stream_)
+{
+    if (n_images < 0) return NSC_EINVAL;
+    if (rows < 1 || rows > MAXE) return NSC_EUNSUPPORTED;
+    if (n_images == 0) return NSC_OK;
+    if (!imgs || !out || !lut) return NSC_EINVAL;
+    NscEncParams p;
+    nsc_enc_default_params(&p);
+    p.n_elevation = rows;
+    p.target_rows = rows < MAXR ? rows : MAXR;
+    int st;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const EncDev d = make_dev(&p, rows);
+    const LdsPlan lp = lds_plan(d.E, d.R, d.B, FUSED_NW);
+    auto kf = finish_kernel<FUSED_NW>;
+    if ((st = set_lds(kf, lp.total)) != NSC_OK) return st;
+    hipLaunchKernelGGL(kf, dim3(n_images), dim3(FUSED_NW * 64), lp.total, stream,
+                       static_cast<const unsigned *>(nullptr), imgs, 1, d, lut, static_cast<float *>(nullptr),
+                       static_cast<float *>(nullptr), out);
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

@@ -85,11 +85,22 @@ class RangeImageProjector:
 
 def interpolate_range_image(range_image: np.ndarray, method: str = "linear",
                             device="cuda") -> np.ndarray:
-    """range_image.py:15-89 (method='linear') evaluated by the HIP finish stage.
-
-    The kernel interpolates images it scattered itself; a host image is replayed as a cloud of
-    pixel-centre points would not be bit-faithful, so this helper is not offered on the device --
-    the encoder applies interpolation internally (``interpolate_empty=True``)."""
-    raise NotImplementedError(
-        "stand-alone interpolation is not exposed: SpectralEncoder(interpolate_empty=True) "
-        "interpolates inside the fused kernel (csrc/nsc_encoder.hip interp_row)")
+    """range_image.py:15-89 (method='linear') on the device: (rows, 360) image with 0 for empty pixels
+    -> interpolated image, bit-identical to the reference (nsc_interpolate_range_images)."""
+    if method != "linear":
+        raise NotImplementedError("only method='linear' is used by the reference (spectral_encoder.py:221)")
+    from .spectral_encoder import _default_lut
+    dev = torch.device(device)
+    img = torch.as_tensor(np.ascontiguousarray(range_image, dtype=np.float32)).to(dev)
+    batched = img.dim() == 3
+    x = img if batched else img.unsqueeze(0)
+    if x.shape[2] != 360:
+        raise ValueError("range images must have 360 azimuth columns")
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        st = _lib.lib().nsc_interpolate_range_images(_lib.ptr(x), int(x.shape[0]), int(x.shape[1]),
+                                                     _lib.ptr(_default_lut(dev)), _lib.ptr(out),
+                                                     _lib.stream_ptr(dev))
+    _lib.check(st, "nsc_interpolate_range_images")
+    res = out if batched else out[0]
+    return res.cpu().numpy()

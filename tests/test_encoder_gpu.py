@@ -178,3 +178,43 @@ def test_bench_sized_batch_sampled_against_oracle():
     for c in (0, 31, 63):
         host = pts[c * 120000:(c + 1) * 120000].cpu().numpy()
         assert _close(d[c].cpu().numpy(), orc.encode_points(host), 1e-6, 1e-9)
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c)[4:-4] for c in CASES])
+def test_interpolate_range_image_standalone(path):
+    """interpolate_range_image() drop-in (range_image.py:15-89): reference raw image in, reference
+    interpolated image out, bit for bit."""
+    from neural_spectral_codec_amd.encoding.range_image import interpolate_range_image
+    g = np.load(path)
+    out = interpolate_range_image(g["ref_raw"].view(np.float32))
+    assert np.array_equal(out.view(np.uint32), g["ref_interp"])
+
+
+def test_projector_project_matches_reference(golden_dir):
+    from neural_spectral_codec_amd.encoding.range_image import RangeImageProjector
+    g = np.load(os.path.join(golden_dir, "enc_uniform20k.npz"))
+    img, inten = RangeImageProjector(n_elevation=16).project(g["points"], keep_intensity=False)
+    assert inten is None and np.array_equal(img.view(np.uint32), g["ref_raw"])
+
+
+def test_scatter_and_finish_as_separate_launches():
+    """nsc_scatter_clouds + nsc_finish_images == nsc_encode_clouds (bit for bit)."""
+    import ctypes as C
+    from neural_spectral_codec_amd import _lib
+    enc = _enc()
+    pts, off = synth.make_clouds_packed(range(50, 60), 20000, "ring")
+    tp, to = torch.from_numpy(pts).cuda(), torch.from_numpy(off).cuda()
+    ref = enc.encode_points_batch((tp, to))
+    L, p, lut = _lib.lib(), enc._params(), enc._lut(tp.device)
+    for n in (10, 600):                                   # split path and one-workgroup-per-cloud path
+        if n == 600:
+            pts2, off2 = synth.make_clouds_packed(range(600), 1000, "uniform")
+            tp, to = torch.from_numpy(pts2).cuda(), torch.from_numpy(off2).cuda()
+            ref = enc.encode_points_batch((tp, to))
+        sq = torch.empty((n, 16, 360), dtype=torch.int32, device="cuda")
+        out = torch.empty((n, 800), device="cuda")
+        st = _lib.stream_ptr(tp.device)
+        assert L.nsc_scatter_clouds(_lib.ptr(tp), _lib.ptr(to), n, int(tp.shape[0]), 4, p, _lib.ptr(sq), st) == 0
+        assert L.nsc_finish_images(_lib.ptr(sq), n, p, _lib.ptr(lut), _lib.ptr(out), None, None, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)

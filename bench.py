@@ -82,11 +82,18 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NSC_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a ONE-GPU box (all ranks share cuda:0,
+    # collectives over gloo).  Never used for reported numbers.
+    rehearsal = os.environ.get("NSC_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from neural_spectral_codec_amd import synth
     from neural_spectral_codec_amd import distributed as nd
@@ -134,12 +141,7 @@ def main():
         for k in range(args.steps):
             # the encoder kernel is bracketed by HIP events on the stream it is launched on (torch's
             # current stream) -> live per-launch duration for the roofline object
-            ev[k][0].record()
-            local = _Enc.encode_points_batch((pts, off))
-            ev[k][1].record()
-            desc_all = nd.all_gather_descriptors(local, n_total)
-            path._graph.x = desc_all[path._wlo:path._wlo + path._graph.num_nodes]
-            emb = model(path._graph)
+            desc_all, emb = path.step((pts, off), encoder_events=ev[k])
         sync()
         dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -162,7 +164,8 @@ def main():
             "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds",
             "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
             "config": {
                 "workload": f"{n_local} clouds x {N_POINTS} points per GPU (BASELINE.json configs[1]) "
                             f"+ 3-layer GAT forward over the {n_local}-keyframe temporal chain "

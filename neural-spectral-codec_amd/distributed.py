@@ -87,31 +87,82 @@ class ShardedDescriptorPath:
     """encode (local shard) -> all-gather descriptors -> GNN on shard + halo (local rows out).
 
     ``encoder`` needs ``encode_points_batch(clouds)``; ``gnn`` is called as ``gnn(data)``.  The graph
-    of a fixed (n_total, poses) layout is built once and reused: only ``x`` changes per step."""
+    of a fixed (n_total, poses) layout is built once and reused: only ``x`` changes per step.
+
+    With equal shards the GNN does not wait for the full all-gather: the ranks first exchange only
+    their 2 x halo boundary rows (one tiny all-gather, 38 KB per rank for halo 6), the big all-gather
+    (3.3 MB per rank at 1 024 keyframes) is issued asynchronously and overlaps the GNN forward, and the
+    step waits for it at the end (the gathered matrix is what stage-1 retrieval consumes)."""
 
     def __init__(self, encoder, gnn, n_total: int, poses=None, temporal_neighbors: int = 5,
-                 n_layers: int = 3, group=None):
+                 n_layers: int = 3, group=None, overlap: bool = True):
         self.encoder, self.gnn, self.group = encoder, gnn, group
         self.n_total, self.poses = n_total, poses
         self.M, self.L = temporal_neighbors, n_layers
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.lo, self.hi = shard_range(n_total, self.rank, self.world)
+        self.halo = n_layers * (temporal_neighbors // 2)
+        n_local = self.hi - self.lo
+        self.overlap = (overlap and self.world > 1 and n_total % self.world == 0 and n_local >= self.halo)
         self._graph = None
         self._own0 = 0
+        self._wlo = 0
+        self._desc_all = None
 
-    def step(self, clouds):
+    def _window_graph(self, like: torch.Tensor):
+        """Sub-chain graph over [lo-halo, hi+halo) n [0, n_total) with a placeholder x."""
+        wlo, whi = halo_window(self.n_total, self.lo, self.hi, self.L, self.M)
+        n = whi - wlo
+        edges = chain_edges(n, self.M)
+        dev = like.device
+        edge_index = (torch.from_numpy(edges.T.copy()).to(dev) if len(edges)
+                      else torch.empty((2, 0), dtype=torch.long, device=dev))
+        edge_attr = None
+        if self.poses is not None and len(edges):
+            edge_attr = torch.from_numpy(edge_features(self.poses[wlo:whi], edges)).to(dev)
+        self._graph = Data(x=None, edge_index=edge_index, edge_attr=edge_attr, num_nodes=n)
+        self._own0, self._wlo = self.lo - wlo, wlo
+
+    def step(self, clouds, encoder_events=None):
         """clouds: this rank's shard (list of arrays or (points, offsets) device tensors).
-        Returns (all descriptors (n_total, D), enhanced embeddings of the owned rows (hi-lo, D))."""
+        Returns (all descriptors (n_total, D), enhanced embeddings of the owned rows (hi-lo, D)).
+        ``encoder_events``: optional (start, end) torch.cuda.Event pair recorded around the encoder launch."""
+        if encoder_events is not None:
+            encoder_events[0].record()
         local = self.encoder.encode_points_batch(clouds)
-        desc_all = all_gather_descriptors(local, self.n_total, self.group)
+        if encoder_events is not None:
+            encoder_events[1].record()
         if self._graph is None:
-            self._graph, self._own0 = shard_graph(desc_all, self.lo, self.hi, self.poses, self.L, self.M)
-            self._wlo = self.lo - self._own0
+            self._window_graph(local)
+        n_local, h = self.hi - self.lo, self.halo
+        work = None
+        if self.overlap:
+            # 1. boundary rows only (tiny, blocking): [first h rows | last h rows] of every rank
+            d = int(local.shape[1])
+            mine = torch.cat([local[:h], local[n_local - h:]], 0)
+            edges_all = torch.empty((self.world * 2 * h, d), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(edges_all, mine, group=self.group)
+            # 2. the full matrix, asynchronously
+            if self._desc_all is None or self._desc_all.shape[0] != self.n_total:
+                self._desc_all = torch.empty((self.n_total, d), dtype=local.dtype, device=local.device)
+            work = dist.all_gather_into_tensor(self._desc_all, local.contiguous(), group=self.group,
+                                               async_op=True)
+            parts = []
+            if self.rank > 0:                       # previous rank's last h rows
+                parts.append(edges_all[(self.rank - 1) * 2 * h + h:(self.rank - 1) * 2 * h + 2 * h])
+            parts.append(local)
+            if self.rank < self.world - 1:          # next rank's first h rows
+                parts.append(edges_all[(self.rank + 1) * 2 * h:(self.rank + 1) * 2 * h + h])
+            self._graph.x = torch.cat(parts, 0) if len(parts) > 1 else local
+            desc_all = self._desc_all
         else:
+            desc_all = all_gather_descriptors(local, self.n_total, self.group)
             self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]
         emb = self.gnn(self._graph)
-        return desc_all, emb[self._own0:self._own0 + (self.hi - self.lo)]
+        if work is not None:
+            work.wait()
+        return desc_all, emb[self._own0:self._own0 + n_local]
 
 
 def all_reduce_gradients(params, group=None, average: bool = False):

@@ -50,6 +50,7 @@ def _worker(rank, world, port, n_total, q):
         go.randomize_bn_stats(model)
         poses = synth.make_pose_chain(n_total, 3)
         path = nd.ShardedDescriptorPath(OracleEncoder(), OracleGnn(model), n_total, poses)
+        assert path.overlap == (n_total % world == 0)     # 24: boundary exchange + async all-gather; 21: plain
         lo, hi = path.lo, path.hi
         clouds = [synth.make_cloud(1000 + i, 1500, "uniform") for i in range(lo, hi)]
         for _ in range(2):                                   # second step reuses the cached graph
@@ -59,9 +60,8 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [24, 21])
-def test_two_rank_gloo_matches_single_process(n_total):
-    world = 2
+@pytest.mark.parametrize("n_total,world", [(24, 2), (21, 2), (36, 3)])
+def test_multi_rank_gloo_matches_single_process(n_total, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -252,6 +252,26 @@ size_t nsc_topk_workspace_bytes(int32_t Q, int32_t N, int32_t k);
 int nsc_topk_smallest(const float *dist, int32_t Q, int32_t N, int32_t k, int64_t *idx, float *val,
                       void *ws, size_t ws_bytes, void *stream);
 
+/* Hard-negative triplet mining inside ONE sequence: replaces
+ * TripletMiner._mine_sequence_triplets / _select_hard_negative (reference src/gnn/triplet_miner.py
+ * :141-229, :314-359).  Members of the sequence are rows 0..n-1 in temporal order. */
+typedef struct NscMineParams {
+    double   positive_distance_max;   /* 5.0   triplet_miner.py:43 */
+    double   negative_distance_min;   /* 10.0  :45 */
+    double   negative_distance_max;   /* 50.0  :46 */
+    int32_t  positive_temporal_min;   /* 30    :44 */
+    int32_t  negative_temporal_min;   /* 30    :47 */
+    int32_t  strategy;                /* 0 = "hard" (argmin W1), 1 = "random" */
+    int32_t  triplets_per_anchor;
+    uint64_t seed;                    /* counter-based choice of the positive (np.random.choice in the reference) */
+} NscMineParams;
+/* positions (n,3) float64 translations; cdf (n,dim) = nsc_w1_cdf(descriptors, divide_plain = 1);
+ * out_pos / out_neg (n, triplets_per_anchor) local row indices or -1 when the anchor has no positive
+ * or no negative candidate; counts (n,2) = [#positive, #negative candidates]. */
+int nsc_mine_triplets(const double *positions, const float *cdf, int32_t n, int32_t dim,
+                      const NscMineParams *mp, int32_t *out_pos, int32_t *out_neg, int32_t *counts,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,14 @@ class GatTrainCfg(C.Structure):
                 ("update_running_stats", C.c_int32)]
 
 
+class MineParams(C.Structure):
+    """struct NscMineParams"""
+    _fields_ = [("positive_distance_max", C.c_double), ("negative_distance_min", C.c_double),
+                ("negative_distance_max", C.c_double), ("positive_temporal_min", C.c_int32),
+                ("negative_temporal_min", C.c_int32), ("strategy", C.c_int32),
+                ("triplets_per_anchor", C.c_int32), ("seed", C.c_uint64)]
+
+
 class GatGradLayer(C.Structure):
     """struct NscGatGradLayer"""
     _fields_ = [(n, C.c_void_p) for n in (
@@ -104,6 +112,7 @@ SYMBOLS = {
                                    C.POINTER(GatGrads), _vp, _sz, _vp]),
     "nsc_w1_cdf": (C.c_int, [_vp, _i32, _i32, C.c_float, _i32, _vp, _vp]),
     "nsc_w1_distances": (C.c_int, [_vp, _i32, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, _vp, _vp]),
+    "nsc_mine_triplets": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(MineParams), _vp, _vp, _vp, _vp]),
     "nsc_topk_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "nsc_topk_smallest": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "nsc_triplet_workspace_bytes": (_sz, [_i32]),

@@ -195,6 +195,112 @@ __global__ __launch_bounds__(256) void topk_stage2_kernel(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// hard-negative triplet mining inside one sequence
+//   TripletMiner._mine_sequence_triplets  src/gnn/triplet_miner.py:141-229
+//   TripletMiner._select_hard_negative    src/gnn/triplet_miner.py:314-359
+// One wavefront per anchor.  Candidates are found by brute force over the sequence with float64
+// distances (the reference asks a cKDTree the same inclusive-radius questions); the hard negative is
+// the candidate with the smallest W1(anchor, candidate) = L1 of the pre-normalised CDF rows.
+// ---------------------------------------------------------------------------------------------
+struct MineParams {
+    double pos_dmax, neg_dmin, neg_dmax;
+    int pos_tmin, neg_tmin;
+    int strategy;              // 0 hard (argmin W1), 1 random
+    int per_anchor;            // triplets per anchor
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ unsigned mine_hash(unsigned long long seed, unsigned a, unsigned k)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)a * 1315423911ull + k + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+
+// index of the r-th set candidate (0-based) among `ok(lo)` over lo = 0..n-1, by one wave
+template <class F>
+__device__ __forceinline__ int nth_candidate(int n, int lane, int r, F ok)
+{
+    int seen = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int lo = c0 + lane;
+        const unsigned long long m = __ballot(lo < n && ok(lo));
+        const int cnt = __popcll(m);
+        if (r < seen + cnt) {
+            int need = r - seen;                 // need-th set bit of m
+            unsigned long long mm = m;
+            for (int t = 0; t < need; ++t) mm &= mm - 1;
+            return c0 + __ffsll((long long)mm) - 1;
+        }
+        seen += cnt;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void mine_kernel(const double *__restrict__ pos, const float *__restrict__ cdf,
+                                                   int n, int D, MineParams p, int *__restrict__ out_pos,
+                                                   int *__restrict__ out_neg, int *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63, la = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (la >= n) return;
+    const double ax = pos[la * 3], ay = pos[la * 3 + 1], az = pos[la * 3 + 2];
+    auto dist = [&](int lo) {
+        const double dx = pos[lo * 3] - ax, dy = pos[lo * 3 + 1] - ay, dz = pos[lo * 3 + 2] - az;
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    auto is_pos = [&](int lo) {                        // :177-184
+        return lo != la && abs(lo - la) >= p.pos_tmin && dist(lo) <= p.pos_dmax;
+    };
+    auto is_neg = [&](int lo) {                        // :186-201 (inside the outer ball, not inside the inner)
+        if (lo == la || abs(lo - la) < p.neg_tmin) return false;
+        const double d = dist(lo);
+        return d <= p.neg_dmax && !(d <= p.neg_dmin);
+    };
+    int npos = 0, nneg = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int lo = c0 + lane;
+        npos += __popcll(__ballot(lo < n && is_pos(lo)));
+        nneg += __popcll(__ballot(lo < n && is_neg(lo)));
+    }
+    if (lane == 0) { counts[la * 2] = npos; counts[la * 2 + 1] = nneg; }
+    if (npos == 0 || nneg == 0) {                      // :208-209
+        for (int k = lane; k < p.per_anchor; k += 64) { out_pos[la * p.per_anchor + k] = -1; out_neg[la * p.per_anchor + k] = -1; }
+        return;
+    }
+    // hard negative: argmin W1 over the candidates, (distance, index) order
+    int hard = -1;
+    if (p.strategy == 0) {
+        float best = INFINITY;
+        const float *ca = cdf + (long long)la * D;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int lo = c0 + lane;
+            unsigned long long m = __ballot(lo < n && is_neg(lo));
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int cand = c0 + b;
+                const float *cb = cdf + (long long)cand * D;
+                float s = 0.0f;
+                for (int c = lane; c < D; c += 64) s += fabsf(ca[c] - cb[c]);
+                s = wave_sumf(s);
+                if (s < best) { best = s; hard = cand; }
+            }
+        }
+    }
+    for (int k = 0; k < p.per_anchor; ++k) {           // :211-216
+        const int rp = (int)(mine_hash(p.seed, (unsigned)la, 2u * k) % (unsigned)npos);
+        const int pc = nth_candidate(n, lane, rp, is_pos);
+        int nc = hard;
+        if (p.strategy == 1) {
+            const int rn = (int)(mine_hash(p.seed, (unsigned)la, 2u * k + 1u) % (unsigned)nneg);
+            nc = nth_candidate(n, lane, rn, is_neg);
+        }
+        if (lane == 0) { out_pos[la * p.per_anchor + k] = pc; out_neg[la * p.per_anchor + k] = nc; }
+    }
+}
+
 int per_of(int D) { int p = ((D + 63) / 64 + 3) / 4 * 4; return p < 4 ? 4 : p; }
 
 }  // namespace
@@ -231,6 +337,23 @@ int nsc_w1_distances(const float *db, int32_t N, int32_t D, float eps, const flo
     case 12: hipLaunchKernelGGL(w1_dist_kernel<12>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
     default: hipLaunchKernelGGL(w1_dist_kernel<16>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
     }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_mine_triplets(const double *positions, const float *cdf, int32_t n, int32_t D, const NscMineParams *mp,
+                      int32_t *out_pos, int32_t *out_neg, int32_t *counts, void *stream_)
+{
+    if (!mp || n < 0 || D < 1) return NSC_EINVAL;
+    if (mp->strategy != 0 && mp->strategy != 1) return NSC_EUNSUPPORTED;
+    if (mp->triplets_per_anchor < 1) return NSC_EINVAL;
+    if (n == 0) return NSC_OK;
+    if (!positions || !cdf || !out_pos || !out_neg || !counts) return NSC_EINVAL;
+    MineParams p;
+    p.pos_dmax = mp->positive_distance_max; p.neg_dmin = mp->negative_distance_min; p.neg_dmax = mp->negative_distance_max;
+    p.pos_tmin = mp->positive_temporal_min; p.neg_tmin = mp->negative_temporal_min;
+    p.strategy = mp->strategy; p.per_anchor = mp->triplets_per_anchor; p.seed = mp->seed;
+    hipLaunchKernelGGL(mine_kernel, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), positions, cdf, n, D,
+                       p, out_pos, out_neg, counts);
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

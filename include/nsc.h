@@ -272,6 +272,20 @@ int nsc_mine_triplets(const double *positions, const float *cdf, int32_t n, int3
                       const NscMineParams *mp, int32_t *out_pos, int32_t *out_neg, int32_t *counts,
                       void *stream);
 
+/* Validation recall for loop closure: the pieces of
+ * GNNTrainer._compute_recall_loop_closure (reference src/gnn/trainer.py:306-387).
+ *   nsc_revisit_queries: first_revisit[i] = first j >= i + skip_frames with |p_i - p_j| < thr, else -1  (:342-348)
+ *   nsc_pairwise_l2    : dist (Q,n) = euclidean embedding distance of query q to every c with |c - q| > skip_frames,
+ *                        +inf for the excluded temporal neighbours (:355-370); feed to nsc_topk_smallest
+ *   nsc_recall_rank    : rank[q] = 1-based position of the first of the k nearest candidates that lies within
+ *                        thr of the query pose, 0 if none (:376-383)  ->  recall@K = mean(0 < rank <= K) */
+int nsc_revisit_queries(const double *positions, int32_t n, int32_t skip_frames, double distance_threshold,
+                        int32_t *first_revisit, void *stream);
+int nsc_pairwise_l2(const float *emb, const int32_t *query_idx, int32_t Q, int32_t n, int32_t dim,
+                    int32_t skip_frames, float *dist, void *stream);
+int nsc_recall_rank(const double *positions, const int32_t *query_idx, const int64_t *topk_idx, int32_t Q,
+                    int32_t k, double distance_threshold, int32_t *rank, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

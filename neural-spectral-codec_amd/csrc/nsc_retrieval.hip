@@ -301,6 +301,68 @@ __global__ __launch_bounds__(256) void mine_kernel(const double *__restrict__ po
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// validation recall for loop closure
+//   GNNTrainer._compute_recall_loop_closure   src/gnn/trainer.py:306-387
+// ---------------------------------------------------------------------------------------------
+// first j >= i + skip with |p_i - p_j| < thr  -> query j revisits i (trainer.py:342-348); -1 if none
+__global__ __launch_bounds__(256) void revisit_kernel(const double *__restrict__ pos, int n, int skip, double thr,
+                                                      int *__restrict__ first)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = pos[i * 3], y = pos[i * 3 + 1], z = pos[i * 3 + 2];
+    int r = -1;
+    for (int j = i + skip; j < n; ++j) {
+        const double dx = pos[j * 3] - x, dy = pos[j * 3 + 1] - y, dz = pos[j * 3 + 2] - z;
+        if (sqrt(dx * dx + dy * dy + dz * dz) < thr) { r = j; break; }
+    }
+    first[i] = r;
+}
+
+// dist[q][c] = |e_q - e_c|_2 for candidates with |c - q| > skip (trainer.py:363-370), +inf otherwise.
+// grid (ceil(n/64), Q): one wave per (query, 16 candidates).
+__global__ __launch_bounds__(256) void pair_l2_kernel(const float *__restrict__ emb, const int *__restrict__ qidx,
+                                                      int n, int D, int skip, float *__restrict__ dist)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.y, q = qidx[qi];
+    const int c0 = (blockIdx.x * 4 + wave) * 16;
+    const float *eq = emb + (long long)q * D;
+    for (int t = 0; t < 16; ++t) {
+        const int c = c0 + t;
+        if (c >= n) break;
+        float out = INFINITY;
+        if (abs(c - q) > skip) {
+            const float *ec = emb + (long long)c * D;
+            double s = 0.0;
+            for (int k = lane; k < D; k += 64) { const float d = eq[k] - ec[k]; s += (double)d * (double)d; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            out = (float)sqrt(s);
+        }
+        if (lane == 0) dist[(long long)qi * n + c] = out;
+    }
+}
+
+// rank[qi] = 1-based position of the first of the k nearest candidates lying within thr of the query, 0 if none
+__global__ __launch_bounds__(256) void recall_rank_kernel(const double *__restrict__ pos, const int *__restrict__ qidx,
+                                                          const long long *__restrict__ topk_idx, int Q, int k, double thr,
+                                                          int *__restrict__ rank)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= Q) return;
+    const int q = qidx[qi];
+    int r = 0;
+    for (int t = 0; t < k; ++t) {
+        const long long c = topk_idx[(long long)qi * k + t];
+        if (c < 0) break;
+        const double dx = pos[c * 3] - pos[q * 3], dy = pos[c * 3 + 1] - pos[q * 3 + 1], dz = pos[c * 3 + 2] - pos[q * 3 + 2];
+        if (sqrt(dx * dx + dy * dy + dz * dz) < thr) { r = t + 1; break; }
+    }
+    rank[qi] = r;
+}
+
 int per_of(int D) { int p = ((D + 63) / 64 + 3) / 4 * 4; return p < 4 ? 4 : p; }
 
 }  // namespace
@@ -337,6 +399,40 @@ int nsc_w1_distances(const float *db, int32_t N, int32_t D, float eps, const flo
     case 12: hipLaunchKernelGGL(w1_dist_kernel<12>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
     default: hipLaunchKernelGGL(w1_dist_kernel<16>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
     }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_revisit_queries(const double *positions, int32_t n, int32_t skip_frames, double distance_threshold,
+                        int32_t *first_revisit, void *stream_)
+{
+    if (n < 0 || skip_frames < 0) return NSC_EINVAL;
+    if (n == 0) return NSC_OK;
+    if (!positions || !first_revisit) return NSC_EINVAL;
+    hipLaunchKernelGGL(revisit_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), positions, n,
+                       skip_frames, distance_threshold, first_revisit);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_pairwise_l2(const float *emb, const int32_t *query_idx, int32_t Q, int32_t n, int32_t D, int32_t skip_frames,
+                    float *dist, void *stream_)
+{
+    if (Q < 0 || n < 0 || D < 1) return NSC_EINVAL;
+    if (Q == 0 || n == 0) return NSC_OK;
+    if (!emb || !query_idx || !dist) return NSC_EINVAL;
+    if (Q > 65535) return NSC_EUNSUPPORTED;              // grid.y; callers chunk the queries
+    hipLaunchKernelGGL(pair_l2_kernel, dim3((n + 63) / 64, Q), dim3(256), 0, static_cast<hipStream_t>(stream_), emb, query_idx,
+                       n, D, skip_frames, dist);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_recall_rank(const double *positions, const int32_t *query_idx, const int64_t *topk_idx, int32_t Q, int32_t k,
+                    double distance_threshold, int32_t *rank, void *stream_)
+{
+    if (Q < 0 || k < 1) return NSC_EINVAL;
+    if (Q == 0) return NSC_OK;
+    if (!positions || !query_idx || !topk_idx || !rank) return NSC_EINVAL;
+    hipLaunchKernelGGL(recall_rank_kernel, dim3((Q + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), positions,
+                       query_idx, reinterpret_cast<const long long *>(topk_idx), Q, k, distance_threshold, rank);
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

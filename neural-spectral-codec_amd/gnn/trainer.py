@@ -80,6 +80,64 @@ class GNNTrainer:
         self.batch_size, self.accumulation_steps = batch_size, accumulation_steps
         self.global_step = 0
 
+    # -- validation (trainer.py:238-387) ------------------------------------------------------
+    def _recall_ranks(self, embeddings: torch.Tensor, poses: np.ndarray, max_k: int,
+                      distance_threshold: float, skip_frames: int):
+        """Rank of the first correct candidate among the max_k nearest, per loop-closure query."""
+        from ..retrieval.wasserstein import _topk
+        L = _lib.lib()
+        dev = embeddings.device
+        emb = embeddings.detach().float().contiguous()
+        n, d = int(emb.shape[0]), int(emb.shape[1])
+        pos = torch.as_tensor(np.asarray(poses)[:, :3, 3].astype(np.float64)).to(dev).contiguous()
+        first = torch.empty(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.nsc_revisit_queries(_lib.ptr(pos), n, skip_frames, float(distance_threshold),
+                                             _lib.ptr(first), _lib.stream_ptr(dev)), "nsc_revisit_queries")
+        qidx = first[first >= 0].contiguous()                     # one query per earlier frame i (:342-348)
+        nq = int(qidx.numel())
+        if nq == 0:
+            return torch.empty(0, dtype=torch.int32, device=dev)
+        ranks = torch.empty(nq, dtype=torch.int32, device=dev)
+        k = min(max_k, n)
+        chunk = 4096
+        for q0 in range(0, nq, chunk):
+            qs = qidx[q0:q0 + chunk].contiguous()
+            dist = torch.empty((int(qs.numel()), n), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.nsc_pairwise_l2(_lib.ptr(emb), _lib.ptr(qs), int(qs.numel()), n, d, skip_frames,
+                                             _lib.ptr(dist), _lib.stream_ptr(dev)), "nsc_pairwise_l2")
+            idx, val = _topk(dist, k)
+            idx = torch.where(torch.isinf(val), torch.full_like(idx, -1), idx)    # fewer than k candidates
+            with torch.cuda.device(dev):
+                _lib.check(L.nsc_recall_rank(_lib.ptr(pos), _lib.ptr(qs), _lib.ptr(idx.contiguous()),
+                                             int(qs.numel()), k, float(distance_threshold),
+                                             _lib.ptr(ranks[q0:q0 + chunk]), _lib.stream_ptr(dev)),
+                           "nsc_recall_rank")
+        return ranks
+
+    def _compute_recall_loop_closure(self, embeddings, poses: np.ndarray, k: int,
+                                     distance_threshold: float, skip_frames: int = 30):
+        """trainer.py:306-387 -> (recall@k, n_queries)."""
+        if not isinstance(embeddings, torch.Tensor):
+            embeddings = torch.as_tensor(np.asarray(embeddings), dtype=torch.float32).to(self.device)
+        ranks = self._recall_ranks(embeddings, poses, k, distance_threshold, skip_frames)
+        nq = int(ranks.numel())
+        if nq == 0:
+            return 0.0, 0
+        return float(((ranks > 0) & (ranks <= k)).sum().item()) / nq, nq
+
+    def validate(self, val_graph, val_poses: np.ndarray, distance_threshold: float = 5.0,
+                 skip_frames: int = 30):
+        """trainer.py:238-304: eval forward + loop-closure recall@1/5/10 (one top-10 pass serves all three)."""
+        self.model.eval()
+        with torch.no_grad():
+            embeddings = self.model(val_graph.to(self.device))
+        ranks = self._recall_ranks(embeddings, val_poses, 10, distance_threshold, skip_frames)
+        nq = int(ranks.numel())
+        rec = lambda k: (float(((ranks > 0) & (ranks <= k)).sum().item()) / nq) if nq else 0.0   # noqa: E731
+        return {'recall@1': rec(1), 'recall@5': rec(5), 'recall@10': rec(10), 'n_queries': nq}
+
     def train_batches(self, graph, triplets: Sequence) -> float:
         """trainer.py:186-231 for an (n,3) array of (anchor, positive, negative) triplets."""
         self.model.train()

@@ -177,6 +177,15 @@ class SpectralEncoder(nn.Module):
             off = clouds[1].to(device=dev, dtype=torch.int64).contiguous()
             n = int(off.numel()) - 1
             total = int(pts.shape[0])
+        elif len(clouds) > 0 and all(isinstance(c, torch.Tensor) for c in clouds):
+            ts = [c.detach().to(device=dev, dtype=torch.float32) for c in clouds]       # device tensors stay put
+            n = len(ts)
+            if len({int(t.shape[1]) for t in ts}) != 1:
+                raise ValueError("all clouds of a batch must have the same width (3 or 4)")
+            pts, stride = _as_points(ts[0] if n == 1 else torch.cat(ts, 0), dev)
+            off = torch.tensor(np.concatenate([[0], np.cumsum([int(t.shape[0]) for t in ts])]),
+                               dtype=torch.int64, device=dev)
+            total = int(pts.shape[0])
         else:
             arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
             n = len(arrs)

@@ -5,6 +5,6 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_prof.log 2>&1
+python $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $R/gpurun_out/${TAG}_prof.log 2>&1
 tail -c 3000 $R/gpurun_out/${TAG}_bench.json

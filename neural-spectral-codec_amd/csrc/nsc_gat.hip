@@ -6,12 +6,12 @@
 //
 // Kernels
 //   csr_*                edge list -> CSR by target with PyG's self-loop convention (deterministic order)
-//   gat_prepare_kernel   weights-only folding: u_src = W^T att_src, u_dst = W^T att_dst (so the two
+//   gat_fold_kernel      weights-only folding: u_src = W^T att_src, u_dst = W^T att_dst (so the two
 //                        attention dot products ride along the lin GEMM as 2 extra output columns),
 //                        v = W_edge^T att_edge (edge term becomes an edge_dim-long dot product)
-//   gemm_nt_kernel       C = A * B^T on v_mfma_f32_16x16x4_f32 (exact f32), operands straight from
-//                        L2/L1 as 16-byte loads (the GEMMs are 0.2-0.8 GFLOP: latency-, not FLOP-bound),
-//                        fused bias / BatchNorm(eval) / ReLU / residual epilogue
+//   gemm_nt_kernel       C = A * B^T on v_mfma_f32_16x16x4_f32 (exact f32), LDS-staged 16*ACC x 64 x 64
+//                        tiles fed from a register ring of prefetched chunks (the GEMMs are 0.2-0.8 GFLOP:
+//                        latency-, not FLOP-bound), fused bias / BatchNorm(eval) / ReLU / residual epilogue
 //   gat_aggregate_kernel one wavefront per target node: leaky-relu logits, wave-shuffle softmax over the
 //                        node's in-edges, alpha-weighted sum of neighbour rows (float4 per lane), fused
 //                        bias + BatchNorm(eval) + ReLU + residual epilogue
@@ -227,61 +227,69 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 #pragma unroll
     for (int h = 0; h < ACC; ++h) acc[h] = zero;
 
-    f32x4 ra[NA], rb[NB];
+    // Register ring of PD chunks: every global load of the next PD chunks is in flight while the current
+    // chunk's MFMAs run, so one L2 round trip is exposed per kernel instead of one per chunk (these GEMMs
+    // are latency-bound: K = 256 is only 4 chunks).  A short last chunk (K % 64 != 0) re-reads valid
+    // columns; those k-blocks are skipped below.
+    constexpr int PD = (ACC == 1) ? 4 : 3;
+    const int nchunks = K / BK + ((K % BK) ? 1 : 0);
+    f32x4 ra[PD][NA], rb[PD][NB];
+    auto load_chunk = [&](int ch, f32x4 (&xa)[NA], f32x4 (&xb)[NB]) {
+        const int kn = ch * BK;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ga[i]);
+        for (int i = 0; i < NA; ++i) {
+            const int c4 = (tid + 256 * i) & 15, k = kn + 4 * c4;
+            xa[i] = *reinterpret_cast<const f32x4 *>(ga[i] + (k + 4 <= K ? kn : K - 4 - 4 * c4));
+        }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(gb[i]);
+        for (int i = 0; i < NB; ++i) {
+            const int c4 = (tid + 256 * i) & 15, k = kn + 4 * c4;
+            xb[i] = *reinterpret_cast<const f32x4 *>(gb[i] + (k + 4 <= K ? kn : K - 4 - 4 * c4));
+        }
+    };
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[0][sa[i]]) = ra[i];
+    for (int s = 0; s < PD; ++s) load_chunk(s < nchunks ? s : nchunks - 1, ra[s], rb[s]);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[0][sb[i]]) = rb[i];
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[0][sa[i]]) = ra[0][i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[0][sb[i]]) = rb[0][i];
+    if (PD < nchunks) load_chunk(PD, ra[0], rb[0]);          // slot 0 is free again
     __syncthreads();
 
-    const int nchunks = K / BK + ((K % BK) ? 1 : 0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int cur = ch & 1;
-        const int kn = (ch + 1) * BK;                      // next chunk (K is a multiple of 16)
-        const bool more = ch + 1 < nchunks;
-        if (more) {
-            // a short last chunk (K % 64 != 0) re-reads valid columns; those k-blocks are skipped below
+    for (int ch0 = 0; ch0 < nchunks; ch0 += PD) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int c4 = (tid + 256 * i) & 15;
-                const int k = kn + 4 * c4;
-                ra[i] = *reinterpret_cast<const f32x4 *>(ga[i] + (k + 4 <= K ? kn : K - 4 - 4 * c4));
-            }
+        for (int s = 0; s < PD; ++s) {
+            const int ch = ch0 + s;
+            if (ch < nchunks) {                                // workgroup-uniform
+                const int cur = ch & 1;
+                const float *as = As[cur], *bs = Bs[cur];
+                const int kleft = K - ch * BK;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int c4 = (tid + 256 * i) & 15;
-                const int k = kn + 4 * c4;
-                rb[i] = *reinterpret_cast<const f32x4 *>(gb[i] + (k + 4 <= K ? kn : K - 4 - 4 * c4));
-            }
-        }
-        const float *as = As[cur], *bs = Bs[cur];
-        const int kleft = K - ch * BK;
+                for (int d = 0; d < BK / 16; ++d) {
+                    if (16 * d < kleft) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
+                        f32x4 av[ACC];
 #pragma unroll
-        for (int d = 0; d < BK / 16; ++d) {
-            if (16 * d < kleft) {                          // wave-uniform
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
-                f32x4 av[ACC];
+                        for (int h = 0; h < ACC; ++h)
+                            av[h] = *reinterpret_cast<const f32x4 *>(&as[(16 * h + r) * LD + 16 * d + 4 * q]);
 #pragma unroll
-                for (int h = 0; h < ACC; ++h)
-                    av[h] = *reinterpret_cast<const f32x4 *>(&as[(16 * h + r) * LD + 16 * d + 4 * q]);
+                        for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                            for (int h = 0; h < ACC; ++h)
+                                acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+                    }
+                }
+                if (ch + 1 < nchunks) {
+                    const int ns = (s + 1) % PD;                // ring slot holding chunk ch + 1 (static)
 #pragma unroll
-                    for (int h = 0; h < ACC; ++h)
-                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+                    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[cur ^ 1][sa[i]]) = ra[ns][i];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[cur ^ 1][sb[i]]) = rb[ns][i];
+                    if (ch + 1 + PD < nchunks) load_chunk(ch + 1 + PD, ra[ns], rb[ns]);
+                }
+                __syncthreads();
             }
         }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[cur ^ 1][sa[i]]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[cur ^ 1][sb[i]]) = rb[i];
-        }
-        __syncthreads();
     }
 
     // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg

@@ -218,3 +218,22 @@ def test_scatter_and_finish_as_separate_launches():
         assert L.nsc_finish_images(_lib.ptr(sq), n, p, _lib.ptr(lut), _lib.ptr(out), None, None, st) == 0
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+def test_full_bench_size_properties():
+    """BASELINE configs[1] at full size (1 024 clouds x 120 000 points, 1.97 GB in HBM), through
+    size-independent properties: rows sum to 1, a cloud's descriptor does not depend on its position in
+    the batch or on its neighbours (reversed batch order gives the reversed result, bit for bit), and
+    sampled clouds equal the oracle."""
+    enc = _enc()
+    n, npts = 1024, 120000
+    pts, off = synth.make_clouds_device(n, npts, "cuda", seed=11)
+    d = enc.encode_points_batch((pts, off))
+    assert torch.allclose(d.sum(1), torch.ones(n, device="cuda"), atol=1e-5)
+    rev = pts.view(n, npts, 4).flip(0).reshape(-1, 4).contiguous()
+    d2 = enc.encode_points_batch((rev, off))
+    assert torch.equal(d2.flip(0), d)
+    del rev, d2
+    for c in (0, 511, 1023):
+        host = pts[c * npts:(c + 1) * npts].cpu().numpy()
+        assert _close(d[c].cpu().numpy(), orc.encode_points(host), 1e-6, 1e-9)

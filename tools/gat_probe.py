@@ -18,7 +18,7 @@ for n in (1024, 4541):
         for _ in range(100): m(g)
         e1.record(); torch.cuda.synchronize()
     print(f"N={n}: {e0.elapsed_time(e1)/100*1e3:.1f} us per forward", flush=True)
-os.environ["NSC_TUNE_GAT_FUSED"] = "0"
+sys.exit(0)
 for n in (1024, 4541):
     torch.manual_seed(0)
     m = create_spectral_gnn(edge_dim=2); go.randomize_bn_stats(m); m = m.to("cuda").eval()

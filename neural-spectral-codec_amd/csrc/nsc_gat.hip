@@ -356,19 +356,44 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
     const float ad = a.a_dst[i];
     const bool use_edge = a.edge_attr && a.v && a.edge_dim > 0;
 
+    // folded edge vector in registers (edge_dim = 2 is the reference's shape)
+    const bool ed2 = use_edge && a.edge_dim == 2;
+    const float v0 = use_edge ? a.v[0] : 0.0f, v1 = ed2 ? a.v[1] : 0.0f;
+
+    // the loads of one entry go out in two dependent rounds only: {src, eid}, then {a_src[j], edge_attr}
     auto logit = [&](int e, int &j) -> float {
         j = a.src[e];
-        float l = a.a_src[j] + ad;
+        const int id = use_edge ? a.eid[e] : 0;
+        float t = 0.0f;
         if (use_edge) {
-            const int id = a.eid[e];
             const float *ea = id >= 0 ? a.edge_attr + (long long)id * a.edge_dim
                                       : a.loop_attr + (long long)i * a.edge_dim;
-            float t = 0.0f;
-            for (int d = 0; d < a.edge_dim; ++d) t = __builtin_fmaf(ea[d], a.v[d], t);
-            l += t;
+            if (ed2) {
+                const float e0 = ea[0], e1 = ea[1];
+                t = __builtin_fmaf(e1, v1, e0 * v0);
+            } else {
+                t = ea[0] * v0;
+                for (int d = 1; d < a.edge_dim; ++d) t = __builtin_fmaf(ea[d], a.v[d], t);
+            }
         }
+        const float l = (a.a_src[j] + ad) + t;
         return l > 0.0f ? l : a.slope * l;                        // leaky_relu
     };
+
+    // epilogue operands do not depend on the gather: their loads go out first and land under it
+    f32x4 ep_bias[CH], ep_w[CH], ep_b[CH], ep_mean[CH], ep_var[CH], ep_res[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = 4 * lane + 256 * c;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const bool in = col < a.H;
+        ep_bias[c] = in ? *reinterpret_cast<const f32x4 *>(a.bias + col) : z;
+        ep_w[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_w + col) : z;
+        ep_b[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_b + col) : z;
+        ep_mean[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_mean + col) : z;
+        ep_var[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_var + col) : z;
+        ep_res[c] = (in && a.resid) ? *reinterpret_cast<const f32x4 *>(a.resid + (long long)i * a.H + col) : z;
+    }
 
     f32x4 acc[CH];
 #pragma unroll
@@ -454,14 +479,14 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
         f32x4 o = acc[c];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float v = o[t] + a.bias[col + t];
+            float v = o[t] + ep_bias[c][t];
             if (a.bn_w) {
-                const float invstd = 1.0f / sqrtf(a.bn_var[col + t] + a.bn_eps);
-                const float sc = invstd * a.bn_w[col + t];
-                v = v * sc + (a.bn_b[col + t] - a.bn_mean[col + t] * sc);
+                const float invstd = 1.0f / sqrtf(ep_var[c][t] + a.bn_eps);
+                const float sc = invstd * ep_w[c][t];
+                v = v * sc + (ep_b[c][t] - ep_mean[c][t] * sc);
             }
             if (a.relu) v = fmaxf(v, 0.0f);
-            if (a.resid) v += a.resid[(long long)i * a.H + col + t];
+            if (a.resid) v += ep_res[c][t];
             o[t] = v;
         }
         *reinterpret_cast<f32x4 *>(a.out + (long long)i * a.H + col) = o;

@@ -286,6 +286,44 @@ int nsc_pairwise_l2(const float *emb, const int32_t *query_idx, int32_t Q, int32
 int nsc_recall_rank(const double *positions, const int32_t *query_idx, const int64_t *topk_idx, int32_t Q,
                     int32_t k, double distance_threshold, int32_t *rank, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Keyframe-side helpers either side of the path.
+ * ------------------------------------------------------------------------------------------ */
+/* Offline temporal graph: replaces the O(N*M) Python loop of build_graph_from_keyframes_batch (reference
+ * src/keyframe/graph_manager.py:515-596).  Edges [i, i+off], off = -M/2..M/2 except 0, node-major in ascending
+ * offset, then two edges [q,m],[m,q] per loop closure (loops (n_loops,2), already range-checked by the host
+ * as :555).  poses (n,4,4) float64 row-major, nullable -> no edge_attr.  edge_index (2,E) int64,
+ * edge_attr (E,2) float32 = [log1p(|t_i - t_j|)/5, arccos(clip((clip(tr(R_j R_i^T),-1,3)-1)/2,-1,1))/pi]. */
+int64_t nsc_chain_graph_num_edges(int32_t n_nodes, int32_t temporal_neighbors, int32_t n_loops);
+int nsc_build_chain_graph(const double *poses, int32_t n_nodes, int32_t temporal_neighbors, const int64_t *loops,
+                          int32_t n_loops, int64_t *edge_index, float *edge_attr, void *stream);
+
+/* 16-bit descriptor wire format: HistogramQuantizer.quantize / dequantize (reference
+ * src/encoding/quantization.py:131-191) for n histograms of dim bins (dim <= 4096; the float32 sums follow
+ * numpy's pairwise order bit for bit), and CompressedDescriptor.to_bytes / from_bytes (:41-110) generalised
+ * from 50 bins to dim: records of nsc_record_bytes(dim) = 2*dim + 120 bytes (220 for 50 bins):
+ * [dim x u16][pose 7 x f32][timestamp f64][keyframe id u32][20-byte hash][60 zero bytes]. */
+int nsc_quantize_descriptors(const float *hist, int32_t n, int32_t dim, float eps, uint16_t *quantized, void *stream);
+int nsc_dequantize_descriptors(const uint16_t *quantized, int32_t n, int32_t dim, float eps, float *hist, void *stream);
+size_t nsc_record_bytes(int32_t dim);
+int nsc_pack_records(const uint16_t *quantized, const float *pose7, const double *timestamps,
+                     const uint32_t *keyframe_ids, const uint8_t *hashes, int32_t n, int32_t dim,
+                     uint8_t *records, void *stream);
+int nsc_unpack_records(const uint8_t *records, int32_t n, int32_t dim, uint16_t *quantized, float *pose7,
+                       double *timestamps, uint32_t *keyframe_ids, uint8_t *hashes, void *stream);
+
+/* Geometric-novelty test of the keyframe selector: compute_overlap (reference src/data/pose_utils.py:323-389,
+ * called from keyframe/criteria.py:123) after its random down-sampling (:340-347, done by the caller) for
+ * n_pairs cloud pairs at once.  points1/points2: packed float32 rows of stride_floats (3 or 4) columns,
+ * offsets (n_pairs+1) int64; transforms (n_pairs,4,4) float64 maps cloud 1 into the frame of cloud 2.
+ * max_pair_points = host-known max over pairs of n1+n2 (<= 12288; the reference caps each cloud at 5000).
+ * counts (n_pairs,3) = [|voxels 1|, |voxels 2|, |intersection|], iou (n_pairs) float64. */
+size_t nsc_voxel_overlap_workspace_bytes(int64_t total_points1, int64_t total_points2);
+int nsc_voxel_overlap(const float *points1, const int64_t *offsets1, const float *points2, const int64_t *offsets2,
+                      int32_t n_pairs, int64_t total_points1, int64_t total_points2, int64_t max_pair_points,
+                      int32_t stride_floats, const double *transforms, double voxel_size, int32_t *counts,
+                      double *iou, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,16 @@ SYMBOLS = {
     "nsc_mine_triplets": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(MineParams), _vp, _vp, _vp, _vp]),
     "nsc_topk_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "nsc_topk_smallest": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_chain_graph_num_edges": (_i64, [_i32, _i32, _i32]),
+    "nsc_build_chain_graph": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "nsc_quantize_descriptors": (C.c_int, [_vp, _i32, _i32, C.c_float, _vp, _vp]),
+    "nsc_dequantize_descriptors": (C.c_int, [_vp, _i32, _i32, C.c_float, _vp, _vp]),
+    "nsc_record_bytes": (_sz, [_i32]),
+    "nsc_pack_records": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "nsc_unpack_records": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nsc_voxel_overlap_workspace_bytes": (_sz, [_i64, _i64]),
+    "nsc_voxel_overlap": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, C.c_double, _vp, _vp,
+                                    _vp, _sz, _vp]),
     "nsc_triplet_workspace_bytes": (_sz, [_i32]),
     "nsc_triplet_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, C.c_float, _vp, _vp, _vp,
                                    _sz, _vp]),

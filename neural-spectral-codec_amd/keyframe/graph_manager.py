@@ -77,11 +77,44 @@ def edge_features(poses: np.ndarray, edges: np.ndarray) -> np.ndarray:
     return np.stack([np.log1p(d32) / 5.0, a32 / np.pi], axis=1).astype(np.float32)
 
 
+def chain_graph_device(n_nodes: int, temporal_neighbors: int, device, poses=None, loop_closures=None):
+    """edge_index (2,E) int64 and edge_attr (E,2) float32 (or None) built on the device by
+    nsc_build_chain_graph: same edge order and arithmetic as graph_manager.py:520-596."""
+    from .. import _lib
+    device = torch.device(device)
+    loops = None
+    if loop_closures:                                                     # range check as graph_manager.py:555
+        ok = [[int(q), int(m)] for q, m in loop_closures if 0 <= q < n_nodes and 0 <= m < n_nodes]
+        if ok:
+            loops = torch.tensor(ok, dtype=torch.int64, device=device)
+    n_loops = 0 if loops is None else int(loops.shape[0])
+    L = _lib.lib()
+    E = int(L.nsc_chain_graph_num_edges(n_nodes, temporal_neighbors, n_loops))
+    edge_index = torch.empty((2, E), dtype=torch.int64, device=device)
+    pd = None
+    edge_attr = None
+    if poses is not None and E > 0:
+        pd = torch.as_tensor(np.ascontiguousarray(np.asarray(poses, dtype=np.float64))
+                             if not isinstance(poses, torch.Tensor) else poses)
+        pd = pd.to(device=device, dtype=torch.float64).reshape(n_nodes, 16).contiguous()
+        edge_attr = torch.empty((E, 2), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        st = L.nsc_build_chain_graph(_lib.ptr(pd), n_nodes, temporal_neighbors, _lib.ptr(loops), n_loops,
+                                     _lib.ptr(edge_index), _lib.ptr(edge_attr), _lib.stream_ptr(device))
+    _lib.check(st, "nsc_build_chain_graph")
+    return edge_index, edge_attr
+
+
 def build_chain_graph(features: torch.Tensor, temporal_neighbors: int = 5, device="cpu",
                       poses: Optional[np.ndarray] = None,
                       loop_closures: Optional[List[Tuple[int, int]]] = None):
-    """Same graph as build_graph_from_keyframes_batch, from a stacked (N,D) feature tensor."""
+    """Same graph as build_graph_from_keyframes_batch, from a stacked (N,D) feature tensor.  On a HIP
+    device the edges and edge features are produced by nsc_build_chain_graph; for device='cpu' (the
+    reference's default, graph moved later with .to()) the vectorised host builder is used."""
     n = int(features.shape[0])
+    if torch.device(device).type == "cuda":
+        edge_index, edge_attr = chain_graph_device(n, temporal_neighbors, device, poses, loop_closures)
+        return Data(x=features.to(device), edge_index=edge_index, edge_attr=edge_attr, num_nodes=n)
     edges = chain_edges(n, temporal_neighbors)
     if loop_closures:                                                     # graph_manager.py:553-558
         extra = [[q, m] for q, m in loop_closures if 0 <= q < n and 0 <= m < n]

@@ -24,7 +24,7 @@ class Params(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src = [os.path.join(_HERE, f) for f in ("nsc_oracle.c", "nsc_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("nsc_oracle.c", "keyframe_oracle.c", "nsc_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -55,6 +55,9 @@ def lib():
         L.nsc_oracle_encode_points.argtypes = [fp, C.c_int64, C.c_int32, pp, ip, fp, fp, fp]
         L.nsc_oracle_encode_clouds.argtypes = [fp, lp, C.c_int32, C.c_int32, pp, ip, fp, fp, fp,
                                                C.c_int32]
+        L.nsc_oracle_voxel_overlap.argtypes = [fp, C.c_int64, fp, C.c_int64, C.c_int32,
+                                               C.POINTER(C.c_double), C.c_double, ip]
+        L.nsc_oracle_voxel_overlap.restype = C.c_double
         _lib = L
     return _lib
 

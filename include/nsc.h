@@ -187,6 +187,12 @@ size_t nsc_gat_workspace_bytes(const NscGatModel *m, int32_t n_nodes);
  *   alpha_out  nullable (n_layers, nnz) attention coefficients (forward_with_attention) */
 int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                     float *out, float *alpha_out, void *ws, size_t ws_bytes, void *stream);
+/* Same forward with launch options.  NSC_GAT_CORESIDENT: every kernel uses 0 bytes of LDS and < 96 VGPRs, so its
+ * workgroups fit on the CUs beside a fully resident nsc_encode_clouds grid (4 workgroups/CU leave 2.3 KB of LDS):
+ * issue it on a second stream to run the GNN of batch k under the encoder of batch k+1.  Bit-identical output. */
+#define NSC_GAT_CORESIDENT 1u
+int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
+                       float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training step of the GNN (BASELINE configs[4]): model.train(); emb = model(graph);

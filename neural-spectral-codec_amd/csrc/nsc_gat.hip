@@ -316,6 +316,96 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-free variant of the same GEMM (NSC_GAT_CORESIDENT): MFMA operands come straight from global
+// memory (every operand element is a 16-byte load of one lane; the four waves of a workgroup re-read
+// the A rows through L1), with a register ring of P k-blocks in flight.  0 bytes of LDS and < 96 VGPRs,
+// so one workgroup fits on a CU next to the four resident workgroups of encode_fused_kernel -- the GNN
+// forward of batch k can then run on a second stream under the encoder of batch k+1.  Same k order and
+// operand assignment as gemm_nt_kernel, so the results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int ACC, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__restrict__ A, int lda,
+                                                             const float *__restrict__ B, int ldb,
+                                                             const float *__restrict__ Bx, int M, int N,
+                                                             int n_main, int K, float *__restrict__ C, int ldc,
+                                                             GemmEpi ep)
+{
+    constexpr int BM = 16 * ACC, P = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 64;
+    const int cb = n0 + wave * 16 + r;
+
+    const float *pa[ACC];
+#pragma unroll
+    for (int h = 0; h < ACC; ++h) {
+        const int gr = m0 + 16 * h + r;
+        pa[h] = A + (long long)(gr < M ? gr : M - 1) * lda + 4 * q;
+    }
+    const int col = cb < N ? cb : N - 1;
+    const float *pb = ((col < n_main) ? B + (long long)col * ldb : Bx + (long long)(col - n_main) * ldb) + 4 * q;
+
+    float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
+    if (EPI != 0) bias = ep.bias[col];
+    if (EPI == 1) {
+        const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
+        bn_scale = invstd * ep.bn_w[col];
+        bn_shift = ep.bn_b[col] - ep.bn_mean[col] * bn_scale;
+    }
+
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[ACC];
+#pragma unroll
+    for (int h = 0; h < ACC; ++h) acc[h] = zero;
+
+    const int nblk = K >> 4;                       // K is a multiple of 16 (check_model)
+    f32x4 ra[P][ACC], rb[P];
+    auto load_blk = [&](int blk, f32x4 (&xa)[ACC], f32x4 &xb) {
+        const int k = blk << 4;
+#pragma unroll
+        for (int h = 0; h < ACC; ++h) xa[h] = *reinterpret_cast<const f32x4 *>(pa[h] + k);
+        xb = *reinterpret_cast<const f32x4 *>(pb + k);
+    };
+#pragma unroll
+    for (int s = 0; s < P; ++s) load_blk(s < nblk ? s : nblk - 1, ra[s], rb[s]);
+    for (int b0 = 0; b0 < nblk; b0 += P) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const int blk = b0 + s;
+            if (blk < nblk) {                      // workgroup-uniform
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int h = 0; h < ACC; ++h)
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[s][h][t], rb[s][t], acc[h], 0, 0, 0);
+                if (blk + P < nblk) load_blk(blk + P, ra[s], rb[s]);
+            }
+        }
+    }
+
+    if (cb >= N) return;
+    const bool main_col = cb < n_main;
+#pragma unroll
+    for (int h = 0; h < ACC; ++h) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = m0 + 16 * h + 4 * q + reg;
+            if (row >= M) continue;
+            float v = acc[h][reg];
+            if (main_col) {
+                if (EPI != 0) v = v + bias;
+                if (EPI == 1) v = fmaxf(v * bn_scale + bn_shift, 0.0f);
+                if (EPI == 2 && ep.resid) v = v + ep.resid[(long long)row * ep.ldr + cb];
+                C[(long long)row * ldc + cb] = v;
+            } else {
+                float *aux = (cb == n_main) ? ep.aux0 : ep.aux1;
+                aux[row] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention + aggregation, one wavefront per target node
 // ---------------------------------------------------------------------------------------------
 struct AggArgs {
@@ -346,7 +436,9 @@ __device__ __forceinline__ float wave_sumf(float v)
     return v;
 }
 
-template <int CH>   // CH = ceil(H / 256): float4 chunks per lane
+// CH = ceil(H / 256): float4 chunks per lane; UR neighbour rows in flight; PRE: epilogue operands prefetched.
+// <CH, 8, true> is the standalone configuration; <1, 4, false> stays under 64 VGPRs for NSC_GAT_CORESIDENT.
+template <int CH, int UR, bool PRE>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -380,20 +472,23 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
         return l > 0.0f ? l : a.slope * l;                        // leaky_relu
     };
 
-    // epilogue operands do not depend on the gather: their loads go out first and land under it
+    // epilogue operands do not depend on the gather: with PRE their loads go out first and land under it
     f32x4 ep_bias[CH], ep_w[CH], ep_b[CH], ep_mean[CH], ep_var[CH], ep_res[CH];
+    auto load_epilogue = [&]() {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int col = 4 * lane + 256 * c;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const bool in = col < a.H;
-        ep_bias[c] = in ? *reinterpret_cast<const f32x4 *>(a.bias + col) : z;
-        ep_w[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_w + col) : z;
-        ep_b[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_b + col) : z;
-        ep_mean[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_mean + col) : z;
-        ep_var[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_var + col) : z;
-        ep_res[c] = (in && a.resid) ? *reinterpret_cast<const f32x4 *>(a.resid + (long long)i * a.H + col) : z;
-    }
+        for (int c = 0; c < CH; ++c) {
+            const int col = 4 * lane + 256 * c;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool in = col < a.H;
+            ep_bias[c] = in ? *reinterpret_cast<const f32x4 *>(a.bias + col) : z;
+            ep_w[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_w + col) : z;
+            ep_b[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_b + col) : z;
+            ep_mean[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_mean + col) : z;
+            ep_var[c] = (in && a.bn_w) ? *reinterpret_cast<const f32x4 *>(a.bn_var + col) : z;
+            ep_res[c] = (in && a.resid) ? *reinterpret_cast<const f32x4 *>(a.resid + (long long)i * a.H + col) : z;
+        }
+    };
+    if (PRE) load_epilogue();
 
     f32x4 acc[CH];
 #pragma unroll
@@ -411,11 +506,11 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
         const float den = wave_sumf(p) + 1e-16f;                  // PyG softmax
         const float al = p / den;
         if (a.alpha_out && e < end) a.alpha_out[e] = al;
-        for (int t0 = 0; t0 < deg; t0 += 8) {                     // 8 neighbour rows in flight
-            f32x4 gv[8][CH];
-            float at[8];
+        for (int t0 = 0; t0 < deg; t0 += UR) {                    // UR neighbour rows in flight
+            f32x4 gv[UR][CH];
+            float at[UR];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UR; ++u) {
                 const int t = t0 + u;
                 at[u] = (t < deg) ? __shfl(al, t & 63) : 0.0f;
                 const int jt = __shfl(j, t & 63);
@@ -427,7 +522,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)                           // entries in edge order, loop last
+            for (int u = 0; u < UR; ++u)                          // entries in edge order, loop last
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     acc[c].x = __builtin_fmaf(at[u], gv[u][c].x, acc[c].x);
@@ -472,6 +567,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
         }
     }
 
+    if (!PRE) load_epilogue();
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int col = 4 * lane + 256 * c;
@@ -535,20 +631,26 @@ int check_model(const NscGatModel *m)
 }
 
 template <int EPI>
-void launch_gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, const float *Bx, int M,
-                 int N, int n_main, int K, float *C, int ldc, const GemmEpi &ep)
+void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const float *B, int ldb, const float *Bx,
+                 int M, int N, int n_main, int K, float *C, int ldc, const GemmEpi &ep)
 {
     // two 16-row accumulators per wave share the B operand; with few row tiles use one so that
     // every SIMD of the chip gets a wave (the GEMMs here are latency-, not throughput-bound)
     const long long wgs2 = (long long)((N + 63) / 64) * ((M + 31) / 32);
-    if (wgs2 >= 384) {
-        dim3 grid((N + 63) / 64, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K,
-                           C, ldc, ep);
+    const bool two = wgs2 >= 384 && !coresident;
+    const dim3 grid((N + 63) / 64, two ? (M + 31) / 32 : (M + 15) / 16);
+    if (coresident) {
+        // one accumulator: 48 VGPRs.  Larger tiles (2 or 4 accumulators, fewer B re-reads) were measured to
+        // disturb the co-running encoder MORE (longer uninterrupted MFMA bursts), DESIGN.md section 7.
+        hipLaunchKernelGGL((gemm_nt_direct_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N,
+                           n_main, K, C, ldc, ep);
     } else {
-        dim3 grid((N + 63) / 64, (M + 15) / 16);
-        hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K,
-                           C, ldc, ep);
+        if (two)
+            hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main,
+                               K, C, ldc, ep);
+        else
+            hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main,
+                               K, C, ldc, ep);
     }
 }
 
@@ -626,6 +728,14 @@ size_t nsc_gat_workspace_bytes(const NscGatModel *m, int32_t n_nodes)
 int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                     float *out, float *alpha_out, void *ws, size_t ws_bytes, void *stream_)
 {
+    return nsc_gat_forward_ex(m, g, x, edge_attr, out, alpha_out, ws, ws_bytes, 0u, stream_);
+}
+
+int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
+                       float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream_)
+{
+    if (flags & ~(uint32_t)NSC_GAT_CORESIDENT) return NSC_EINVAL;
+    const bool cores = (flags & NSC_GAT_CORESIDENT) != 0;
     int stt = check_model(m);
     if (stt != NSC_OK) return stt;
     if (!g || g->n_nodes < 0) return NSC_EINVAL;
@@ -649,7 +759,7 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     ep.bn_w = m->in_bn_w; ep.bn_b = m->in_bn_b; ep.bn_mean = m->in_bn_mean; ep.bn_var = m->in_bn_var;
     ep.bn_eps = m->bn_eps;
     ep.relu = 1;
-    launch_gemm<1>(st, x, m->in_dim, m->in_w, m->in_dim, nullptr, N, H, H, m->in_dim, h0, H, ep);
+    launch_gemm<1>(st, cores, x, m->in_dim, m->in_w, m->in_dim, nullptr, N, H, H, m->in_dim, h0, H, ep);
 
     float *cur = h0, *nxt = h1;
     for (int l = 0; l < L; ++l) {
@@ -659,7 +769,7 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
         GemmEpi e2 = {};
         e2.aux0 = a_src;
         e2.aux1 = a_dst;
-        launch_gemm<0>(st, cur, H, Ly.lin_w, H, auxl, N, H + 2, H, H, G, H, e2);
+        launch_gemm<0>(st, cores, cur, H, Ly.lin_w, H, auxl, N, H + 2, H, H, G, H, e2);
 
         AggArgs a = {};
         a.row_ptr = g->row_ptr; a.src = g->src; a.eid = g->eid;
@@ -678,10 +788,13 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
         a.N = N; a.H = H; a.edge_dim = m->edge_dim;
         const dim3 grid((N + 3) / 4), block(256);
         switch ((H + 255) / 256) {
-        case 1: hipLaunchKernelGGL(gat_aggregate_kernel<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(gat_aggregate_kernel<2>, grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(gat_aggregate_kernel<3>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(gat_aggregate_kernel<4>, grid, block, 0, st, a); break;
+        case 1:
+            if (cores) hipLaunchKernelGGL((gat_aggregate_kernel<1, 4, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((gat_aggregate_kernel<1, 8, true>), grid, block, 0, st, a);
+            break;
+        case 2: hipLaunchKernelGGL((gat_aggregate_kernel<2, 8, true>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((gat_aggregate_kernel<3, 8, true>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((gat_aggregate_kernel<4, 8, true>), grid, block, 0, st, a); break;
         }
         float *t = cur; cur = nxt; nxt = t;
     }
@@ -690,13 +803,13 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     GemmEpi e3 = {};
     e3.bias = m->out_b;
     if (m->residual && m->in_dim == m->out_dim) { e3.resid = x; e3.ldr = m->in_dim; }
-    launch_gemm<2>(st, cur, H, m->out_w, H, nullptr, N, m->out_dim, m->out_dim, H, out, m->out_dim, e3);
+    launch_gemm<2>(st, cores, cur, H, m->out_w, H, nullptr, N, m->out_dim, m->out_dim, H, out, m->out_dim, e3);
     if (m->residual && m->in_dim != m->out_dim) {
         // out += residual_proj(x): second GEMM accumulating through the residual epilogue
         GemmEpi e4 = {};
         e4.bias = m->res_b;
         e4.resid = out; e4.ldr = m->out_dim;
-        launch_gemm<2>(st, x, m->in_dim, m->res_w, m->in_dim, nullptr, N, m->out_dim, m->out_dim, m->in_dim, out,
+        launch_gemm<2>(st, cores, x, m->in_dim, m->res_w, m->in_dim, nullptr, N, m->out_dim, m->out_dim, m->in_dim, out,
                        m->out_dim, e4);
     }
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;

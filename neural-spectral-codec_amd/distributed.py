@@ -92,11 +92,23 @@ class ShardedDescriptorPath:
     With equal shards the GNN does not wait for the full all-gather: the ranks first exchange only
     their 2 x halo boundary rows (one tiny all-gather, 38 KB per rank for halo 6), the big all-gather
     (3.3 MB per rank at 1 024 keyframes) is issued asynchronously and overlaps the GNN forward, and the
-    step waits for it at the end (the gathered matrix is what stage-1 retrieval consumes)."""
+    step waits for it at the end (the gathered matrix is what stage-1 retrieval consumes).
+
+    ``pipeline=True`` software-pipelines consecutive steps on two HIP streams: the encoder of batch k+1 is
+    issued on its own stream right behind the encoder of batch k, and the exchange + GNN of batch k run on a
+    second stream under it (results stay valid for ``_PIPE_BUFFERS - 1`` further steps).  The encoder grid is fully resident (4 workgroups per CU take 157.6 of the
+    160 KB of LDS and 448 of the 512 VGPRs of a SIMD lane), so the GNN is launched in its LDS-free,
+    < 64-VGPR form (``gnn.coresident``, NSC_GAT_CORESIDENT) whose workgroups fit in what is left.  Descriptor
+    buffers are double-buffered; ``step`` returns without waiting and its results are valid after
+    ``synchronize()`` (or once the caller's stream has waited on ``last_event``)."""
 
     def __init__(self, encoder, gnn, n_total: int, poses=None, temporal_neighbors: int = 5,
-                 n_layers: int = 3, group=None, overlap: bool = True):
+                 n_layers: int = 3, group=None, overlap: bool = True, pipeline: bool = False):
         self.encoder, self.gnn, self.group = encoder, gnn, group
+        self.pipeline = pipeline
+        self._k = 0
+        self._streams = None
+        self.last_event = None
         self.n_total, self.poses = n_total, poses
         self.M, self.L = temporal_neighbors, n_layers
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -124,15 +136,70 @@ class ShardedDescriptorPath:
         self._graph = Data(x=None, edge_index=edge_index, edge_attr=edge_attr, num_nodes=n)
         self._own0, self._wlo = self.lo - wlo, wlo
 
+    # -- two-stream software pipeline -----------------------------------------------------------
+    _PIPE_BUFFERS = 4      # descriptor buffers in rotation: the encoder stream never has to wait for the GNN
+
+    def _pipe_setup(self, device):
+        inner = getattr(self.gnn, "gnn", self.gnn)
+        inner.coresident = True
+        sE, sG = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        cur = torch.cuda.current_stream(device)
+        sE.wait_stream(cur)
+        sG.wait_stream(cur)
+        n_local, d = self.hi - self.lo, int(getattr(self.encoder, "output_dim", 800))
+        nb = self._PIPE_BUFFERS
+        self._streams = (sE, sG)
+        self._desc = [torch.empty((n_local, d), dtype=torch.float32, device=device) for _ in range(nb)]
+        self._ev_enc = [torch.cuda.Event() for _ in range(nb)]
+        self._ev_gnn = [torch.cuda.Event() for _ in range(nb)]
+
+    def _step_pipelined(self, clouds, encoder_events):
+        device = self.encoder.alpha.device
+        if self._streams is None:
+            self._pipe_setup(device)
+        sE, sG = self._streams
+        nb = self._PIPE_BUFFERS
+        i = self._k % nb
+        with torch.cuda.stream(sE):
+            # batch k-nb must have been read out of this buffer.  With nb buffers in rotation that GNN pass
+            # has normally finished long ago: ask the host first, so that the encoder stream carries no
+            # cross-stream barrier packet (each one costs ~20 us of idle between two encoder launches).
+            if self._k >= nb and not self._ev_gnn[i].query():
+                sE.wait_event(self._ev_gnn[i])
+            if encoder_events is not None:
+                encoder_events[0].record(sE)
+            local = self.encoder.encode_points_batch(clouds, out=self._desc[i])
+            done = encoder_events[1] if encoder_events is not None else self._ev_enc[i]
+            done.record(sE)
+        with torch.cuda.stream(sG):
+            sG.wait_event(done)
+            res = self._exchange_and_enhance(local)
+            self._ev_gnn[i].record(sG)
+        self.last_event = self._ev_gnn[i]
+        self._k += 1
+        return res
+
+    def synchronize(self):
+        """Make the caller's current stream wait for every step issued so far (pipeline mode)."""
+        if self._streams is not None:
+            cur = torch.cuda.current_stream(self._streams[0].device)
+            cur.wait_stream(self._streams[0])
+            cur.wait_stream(self._streams[1])
+
     def step(self, clouds, encoder_events=None):
         """clouds: this rank's shard (list of arrays or (points, offsets) device tensors).
         Returns (all descriptors (n_total, D), enhanced embeddings of the owned rows (hi-lo, D)).
         ``encoder_events``: optional (start, end) torch.cuda.Event pair recorded around the encoder launch."""
+        if self.pipeline:
+            return self._step_pipelined(clouds, encoder_events)
         if encoder_events is not None:
             encoder_events[0].record()
         local = self.encoder.encode_points_batch(clouds)
         if encoder_events is not None:
             encoder_events[1].record()
+        return self._exchange_and_enhance(local)
+
+    def _exchange_and_enhance(self, local):
         if self._graph is None:
             self._window_graph(local)
         n_local, h = self.hi - self.lo, self.halo

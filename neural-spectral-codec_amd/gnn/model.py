@@ -177,6 +177,9 @@ class SpectralGNN(nn.Module):
             self.residual_proj = None
         self._csr_cache = {}
         self._struct_cache = None          # (key, GatModel, folded tensor)
+        # True: launch the LDS-free, low-VGPR kernel set (NSC_GAT_CORESIDENT) whose workgroups fit beside a
+        # resident encoder grid -- used by distributed.ShardedDescriptorPath(pipeline=True).  Same output.
+        self.coresident = False
 
     # -- plumbing ---------------------------------------------------------------------------
     def __getstate__(self):
@@ -297,10 +300,10 @@ class SpectralGNN(nn.Module):
         nbytes = L.nsc_gat_workspace_bytes(C.byref(m), n)
         ws = _ws(dev, nbytes, "gat")
         with torch.cuda.device(dev):
-            st = L.nsc_gat_forward(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
-                                   _lib.ptr(out), _lib.ptr(alpha), _lib.ptr(ws), nbytes,
-                                   _lib.stream_ptr(dev))
-        _lib.check(st, "nsc_gat_forward")
+            st = L.nsc_gat_forward_ex(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
+                                      _lib.ptr(out), _lib.ptr(alpha), _lib.ptr(ws), nbytes,
+                                      1 if getattr(self, "coresident", False) else 0, _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_gat_forward_ex")
         return out, alpha, csr
 
     # -- reference API ----------------------------------------------------------------------

@@ -316,9 +316,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-free variant of the same GEMM (NSC_GAT_CORESIDENT): MFMA operands come straight from global
-// memory (every operand element is a 16-byte load of one lane; the four waves of a workgroup re-read
-// the A rows through L1), with a register ring of P k-blocks in flight.  0 bytes of LDS and < 96 VGPRs,
+// LDS-free variant of the same GEMM (NSC_GAT_CORESIDENT): operands are loaded from global memory into a
+// register ring of P k-blocks and moved to the MFMA layout by ds_bpermute (the LDS crossbar, no LDS
+// allocation); the four waves of a workgroup re-read the A rows through L1.  0 bytes of LDS and < 64 VGPRs,
 // so one workgroup fits on a CU next to the four resident workgroups of encode_fused_kernel -- the GNN
 // forward of batch k can then run on a second stream under the encoder of batch k+1.  Same k order and
 // operand assignment as gemm_nt_kernel, so the results are bit-identical.
@@ -336,14 +336,31 @@ __global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__rest
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 64;
     const int cb = n0 + wave * 16 + r;
 
+    // Load mapping: lane L fetches 16 bytes of row L >> 2 at k offset 4 (L & 3), so 4 neighbouring lanes read
+    // 64 contiguous bytes and a 16-lane quad touches 4 cache lines.  (Loading in the MFMA operand layout
+    // instead -- row L & 15, offset 4 (L >> 4) -- makes every quad touch 16 lines, 64 L1 requests per load
+    // instruction: those requests, not the MFMAs, were what slowed the co-running encoder.)  One ds_bpermute per
+    // dword then moves the data to the operand layout: lane (r, q) pulls from lane 4 r + q.
+    const int lr = lane >> 2, lq = lane & 3;
+    const int perm = 4 * (4 * r + q);
     const float *pa[ACC];
 #pragma unroll
     for (int h = 0; h < ACC; ++h) {
-        const int gr = m0 + 16 * h + r;
-        pa[h] = A + (long long)(gr < M ? gr : M - 1) * lda + 4 * q;
+        const int gr = m0 + 16 * h + lr;
+        pa[h] = A + (long long)(gr < M ? gr : M - 1) * lda + 4 * lq;
     }
+    const int lcol = (n0 + wave * 16 + lr) < N ? (n0 + wave * 16 + lr) : N - 1;
+    const float *pb = ((lcol < n_main) ? B + (long long)lcol * ldb : Bx + (long long)(lcol - n_main) * ldb) + 4 * lq;
     const int col = cb < N ? cb : N - 1;
-    const float *pb = ((col < n_main) ? B + (long long)col * ldb : Bx + (long long)(col - n_main) * ldb) + 4 * q;
+    auto to_operand = [&](const f32x4 &v) {
+        f32x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float e = v[t];                  // (bit_cast straight from a vector element reads element 0)
+            o[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm, __float_as_int(e)));
+        }
+        return o;
+    };
 
     float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
     if (EPI != 0) bias = ep.bias[col];
@@ -373,12 +390,16 @@ __global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__rest
         for (int s = 0; s < P; ++s) {
             const int blk = b0 + s;
             if (blk < nblk) {                      // workgroup-uniform
+                f32x4 xa[ACC];
+#pragma unroll
+                for (int h = 0; h < ACC; ++h) xa[h] = to_operand(ra[s][h]);
+                const f32x4 xb = to_operand(rb[s]);
+                if (blk + P < nblk) load_blk(blk + P, ra[s], rb[s]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int h = 0; h < ACC; ++h)
-                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[s][h][t], rb[s][t], acc[h], 0, 0, 0);
-                if (blk + P < nblk) load_blk(blk + P, ra[s], rb[s]);
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[h][t], xb[t], acc[h], 0, 0, 0);
             }
         }
     }

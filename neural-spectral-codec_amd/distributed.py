@@ -116,11 +116,14 @@ class ShardedDescriptorPath:
         self.lo, self.hi = shard_range(n_total, self.rank, self.world)
         self.halo = n_layers * (temporal_neighbors // 2)
         n_local = self.hi - self.lo
-        self.overlap = (overlap and self.world > 1 and n_total % self.world == 0 and n_local >= self.halo)
+        # pipeline mode hides the whole exchange + GNN under the next encoder: ONE all-gather per step then (every
+        # RCCL kernel has to find room beside a resident encoder grid), no boundary-row pre-exchange
+        self.overlap = (overlap and not pipeline and self.world > 1 and n_total % self.world == 0
+                        and n_local >= self.halo)
         self._graph = None
         self._own0 = 0
         self._wlo = 0
-        self._desc_all = None
+        self._desc_all = {}                # gathered-matrix buffers, one per pipeline slot
 
     def _window_graph(self, like: torch.Tensor):
         """Sub-chain graph over [lo-halo, hi+halo) n [0, n_total) with a placeholder x."""
@@ -211,9 +214,11 @@ class ShardedDescriptorPath:
             edges_all = torch.empty((self.world * 2 * h, d), dtype=local.dtype, device=local.device)
             dist.all_gather_into_tensor(edges_all, mine, group=self.group)
             # 2. the full matrix, asynchronously
-            if self._desc_all is None or self._desc_all.shape[0] != self.n_total:
-                self._desc_all = torch.empty((self.n_total, d), dtype=local.dtype, device=local.device)
-            work = dist.all_gather_into_tensor(self._desc_all, local.contiguous(), group=self.group,
+            slot = (self._k % self._PIPE_BUFFERS) if self.pipeline else 0
+            if slot not in self._desc_all:
+                self._desc_all[slot] = torch.empty((self.n_total, d), dtype=local.dtype, device=local.device)
+            gathered = self._desc_all[slot]
+            work = dist.all_gather_into_tensor(gathered, local.contiguous(), group=self.group,
                                                async_op=True)
             parts = []
             if self.rank > 0:                       # previous rank's last h rows
@@ -222,9 +227,9 @@ class ShardedDescriptorPath:
             if self.rank < self.world - 1:          # next rank's first h rows
                 parts.append(edges_all[(self.rank + 1) * 2 * h:(self.rank + 1) * 2 * h + h])
             self._graph.x = torch.cat(parts, 0) if len(parts) > 1 else local
-            desc_all = self._desc_all
+            desc_all = gathered
         else:
-            desc_all = all_gather_descriptors(local, self.n_total, self.group)
+            desc_all = all_gather_descriptors(local, self.n_total, self.group)    # fresh tensor per step
             self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]
         emb = self.gnn(self._graph)
         if work is not None:

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One-off soak (not part of the test suite): many full-size random clouds through nsc_encode_clouds vs the C
+oracle -- raw and interpolated range images must be bit-identical, descriptors within 1e-6 relative.
+usage: fuzz_encoder.py [n_rounds] [clouds_per_round] [points_per_cloud]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+sys.path.insert(0, os.path.join(R, "oracle"))
+import nsc_oracle                                                               # noqa: E402
+from neural_spectral_codec_amd import synth                                    # noqa: E402
+from neural_spectral_codec_amd.encoding import SpectralEncoder                 # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ncl = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+npts = int(sys.argv[3]) if len(sys.argv) > 3 else 120000
+threads = min(os.cpu_count() or 1, 128)
+enc = SpectralEncoder(n_elevation=16).to("cuda")
+tot_pts = bad_raw = bad_itp = 0
+worst = 0.0
+t0 = time.time()
+for rd in range(rounds):
+    pts, off = synth.make_clouds_device(ncl, npts, "cuda", seed=9000 + rd)
+    if rd % 3 == 1:                                   # lace with non-finite values and out-of-range points
+        idx = torch.randint(0, pts.shape[0], (pts.shape[0] // 997,), device="cuda")
+        pts[idx, rd % 3] = float("nan")
+        idx = torch.randint(0, pts.shape[0], (pts.shape[0] // 1009,), device="cuda")
+        pts[idx, 0] = float("inf")
+    if rd % 3 == 2:                                   # sparse rows: squeeze elevation so that rows stay empty
+        pts[:, 2] *= 0.2
+    desc, raw, itp = enc.encode_points_batch((pts, off), return_images=True)
+    hp, ho = pts.cpu().numpy(), off.cpu().numpy()
+    od, oraw, oitp = nsc_oracle.encode_clouds(hp, ho, n_threads=threads, want_images=True)
+    raw, itp, desc = raw.cpu().numpy(), itp.cpu().numpy(), desc.cpu().numpy()
+    bad_raw += int((raw.view(np.uint32) != oraw.view(np.uint32)).sum())
+    bad_itp += int((itp.view(np.uint32) != oitp.view(np.uint32)).sum())
+    worst = max(worst, float((np.abs(desc - od) / (np.abs(od) + 1e-9)).max()))
+    tot_pts += pts.shape[0]
+    print(f"round {rd}: {ncl} clouds, raw mismatches {bad_raw}, interpolated mismatches {bad_itp}, "
+          f"worst descriptor rel err {worst:.2e}  ({time.time() - t0:.0f} s)", flush=True)
+print(f"TOTAL {tot_pts} points, {rounds * ncl} clouds: raw pixel mismatches {bad_raw}, interpolated {bad_itp}, "
+      f"descriptor rel err {worst:.2e}")
+sys.exit(1 if (bad_raw or bad_itp or worst > 1e-5) else 0)

@@ -252,6 +252,12 @@ int nsc_w1_cdf(const float *hists, int32_t n, int32_t dim, float eps, int32_t di
  * fly).  db_pos (N,3) / q_pos (Q,3) nullable: pairs closer than min_dist get +inf (spatial filter). */
 int nsc_w1_distances(const float *db, int32_t N, int32_t dim, float eps, const float *q_cdf, int32_t Q,
                      const float *db_pos, const float *q_pos, float min_dist, float *dist, void *stream);
+/* Same distances against a database whose rows are already CDFs (= nsc_w1_cdf(db, divide_plain = 0), kept by
+ * WassersteinRetriever next to the raw histograms so that the normalise + prefix-sum is not redone per query).
+ * dim % 4 == 0, both matrices 16-byte aligned.  Q <= 4: HBM-streaming kernel (rows read once, queries in
+ * registers); Q > 4: register-tiled |a-b| kernel (VALU-bound). */
+int nsc_w1_distances_cdf(const float *db_cdf, int32_t N, int32_t dim, const float *q_cdf, int32_t Q,
+                         const float *db_pos, const float *q_pos, float min_dist, float *dist, void *stream);
 /* idx/val (Q, k): the k smallest entries of each row of dist, ascending, ties to the smaller index
  * (k <= 256 and ceil(N/2048)*k <= 4096). */
 size_t nsc_topk_workspace_bytes(int32_t Q, int32_t N, int32_t k);

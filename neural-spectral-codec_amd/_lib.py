@@ -114,6 +114,7 @@ SYMBOLS = {
                                    C.POINTER(GatGrads), _vp, _sz, _vp]),
     "nsc_w1_cdf": (C.c_int, [_vp, _i32, _i32, C.c_float, _i32, _vp, _vp]),
     "nsc_w1_distances": (C.c_int, [_vp, _i32, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, _vp, _vp]),
+    "nsc_w1_distances_cdf": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, C.c_float, _vp, _vp]),
     "nsc_revisit_queries": (C.c_int, [_vp, _i32, _i32, C.c_double, _vp, _vp]),
     "nsc_pairwise_l2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "nsc_recall_rank": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.c_double, _vp, _vp]),

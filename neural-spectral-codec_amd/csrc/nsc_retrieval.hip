@@ -10,6 +10,7 @@
 // streamed once from HBM (3 200 B for 800 bins), normalised and prefix-summed in registers (16 bins per
 // lane + a wave scan of the lane totals), and compared with every query CDF of the batch.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "../../include/nsc.h"
@@ -118,6 +119,186 @@ __global__ __launch_bounds__(256) void w1_dist_kernel(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Distances against a database of PRE-NORMALISED CDF rows (WassersteinRetriever keeps them next to the raw
+// histograms: the database is persistent, its normalise + prefix-sum does not have to be redone per query).
+//
+// w1_stream_kernel<QT>: 1..4 queries.  HBM-bound: the query CDFs sit in registers, every wave walks its
+//   share of the rows with the next row's loads in flight (3 200 B per row, read once).
+// w1_tile_kernel: query batches.  VALU-bound (2 ops per |a - b| element): a 64-row x 64-query tile per
+//   workgroup, 4 x 4 results per thread, k in chunks of 32 staged k-major through LDS -- the structure of a
+//   register-tiled SGEMM with |a - b| in place of a * b.  Each (row, query) sum is accumulated by ONE thread in
+//   ascending k, so it does not depend on the tiling.
+// ---------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(256) void w1_stream_kernel(const float *__restrict__ dbc, int N, int D,
+                                                        const float *__restrict__ qc, int Q,
+                                                        const float *__restrict__ db_pos,
+                                                        const float *__restrict__ q_pos, float min_dist,
+                                                        float *__restrict__ dist)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int nvec = D >> 2;                                   // D % 4 == 0 (checked by the host)
+    constexpr int NV = 4;                                      // float4 chunks per lane: D <= 1024
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 qv[QT][NV];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane + 64 * j;
+            qv[t][j] = (t < Q && c < nvec) ? reinterpret_cast<const f32x4 *>(qc + (long long)t * D)[c] : zero;
+        }
+    auto load = [&](int i, f32x4 (&v)[NV]) {
+        const f32x4 *row = reinterpret_cast<const f32x4 *>(dbc + (long long)i * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = (c < nvec) ? __builtin_nontemporal_load(&row[c]) : zero;
+        }
+    };
+    f32x4 cur[NV], nxt[NV];
+    int i = wave;
+    if (i < N) load(i, cur);
+    for (; i < N; i += nwaves) {
+        const int in = i + nwaves;
+        if (in < N) load(in, nxt);
+        float s[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float a = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                a += fabsf(cur[j].x - qv[t][j].x);
+                a += fabsf(cur[j].y - qv[t][j].y);
+                a += fabsf(cur[j].z - qv[t][j].z);
+                a += fabsf(cur[j].w - qv[t][j].w);
+            }
+            s[t] = wave_sumf(a);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                if (t >= Q) break;
+                float r = s[t];
+                if (db_pos && q_pos) {                          // two_stage_retrieval.py:160-170
+                    const float dx = db_pos[i * 3] - q_pos[t * 3], dy = db_pos[i * 3 + 1] - q_pos[t * 3 + 1],
+                                dz = db_pos[i * 3 + 2] - q_pos[t * 3 + 2];
+                    if (sqrtf(dx * dx + dy * dy + dz * dz) < min_dist) r = INFINITY;
+                }
+                dist[(long long)t * N + i] = r;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) cur[j] = nxt[j];
+    }
+}
+
+constexpr int TL_I = 64, TL_K = 32, TL_LD = 68;               // LDS rows padded to 68 floats
+
+template <int NQ>   // queries per thread: the tile is 64 rows x 16 NQ queries
+__global__ __launch_bounds__(256) void w1_tile_kernel(const float *__restrict__ dbc, int N, int D,
+                                                      const float *__restrict__ qc, int Q,
+                                                      const float *__restrict__ db_pos,
+                                                      const float *__restrict__ q_pos, float min_dist,
+                                                      float *__restrict__ dist)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][TL_K * TL_LD];   // [k][row]
+    __shared__ __attribute__((aligned(16))) float Bs[2][TL_K * TL_LD];   // [k][query]
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    constexpr int TL_Q = 16 * NQ;
+    constexpr int HB = (TL_Q + 31) / 32;                            // staging passes for the query tile
+    const int i0 = blockIdx.x * TL_I, q0 = blockIdx.y * TL_Q;
+    // staging: thread -> (tile row sr / sr + 32, k offset 4 sk): 128 contiguous bytes per 8 threads
+    const int sr = tid >> 3, sk = (tid & 7) * 4;
+    const float *ga[2], *gb[HB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ri = i0 + sr + 32 * h;
+        ga[h] = dbc + (long long)(ri < N ? ri : N - 1) * D + sk;
+    }
+#pragma unroll
+    for (int h = 0; h < HB; ++h) {
+        const int rq = q0 + sr + 32 * h;
+        gb[h] = qc + (long long)(rq < Q ? rq : Q - 1) * D + sk;
+    }
+    const int nchunks = (D + TL_K - 1) / TL_K;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int ch, f32x4 (&ra)[2], f32x4 (&rb)[HB]) {
+        const int k = ch * TL_K + sk;                                // past D: zeros on both sides add |0 - 0|
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            ra[h] = (k + 4 <= D) ? *reinterpret_cast<const f32x4 *>(ga[h] + ch * TL_K) : zero;
+#pragma unroll
+        for (int h = 0; h < HB; ++h)
+            rb[h] = (k + 4 <= D && sr + 32 * h < TL_Q) ? *reinterpret_cast<const f32x4 *>(gb[h] + ch * TL_K) : zero;
+    };
+    auto stage = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rb)[HB]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[buf][(sk + j) * TL_LD + sr + 32 * h] = ra[h][j];
+#pragma unroll
+        for (int h = 0; h < HB; ++h)
+            if (sr + 32 * h < TL_Q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[buf][(sk + j) * TL_LD + sr + 32 * h] = rb[h][j];
+    };
+    float acc[4][NQ];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) acc[a][b] = 0.0f;
+
+    f32x4 ra[2], rb[HB];
+    gload(0, ra, rb);
+    stage(0, ra, rb);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nchunks) gload(ch + 1, ra, rb);
+        const float *as = As[cur], *bs = Bs[cur];
+#pragma unroll 8
+        for (int k = 0; k < TL_K; ++k) {
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(&as[k * TL_LD + 4 * tx]);
+            float bv[NQ];
+#pragma unroll
+            for (int b = 0; b < NQ; ++b) bv[b] = bs[k * TL_LD + NQ * ty + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < NQ; ++b) acc[a][b] += fabsf(av[a] - bv[b]);
+        }
+        if (ch + 1 < nchunks) stage(cur ^ 1, ra, rb);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        const int q = q0 + NQ * ty + b;
+        if (q >= Q) continue;
+        float r[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = i0 + 4 * tx + a;
+            r[a] = acc[a][b];
+            if (db_pos && q_pos && i < N) {
+                const float dx = db_pos[i * 3] - q_pos[q * 3], dy = db_pos[i * 3 + 1] - q_pos[q * 3 + 1],
+                            dz = db_pos[i * 3 + 2] - q_pos[q * 3 + 2];
+                if (sqrtf(dx * dx + dy * dy + dz * dz) < min_dist) r[a] = INFINITY;
+            }
+        }
+        float *o = dist + (long long)q * N + i0 + 4 * tx;
+        if (i0 + 4 * tx + 3 < N && ((reinterpret_cast<uintptr_t>(o) & 15u) == 0)) {
+            *reinterpret_cast<f32x4 *>(o) = f32x4{r[0], r[1], r[2], r[3]};
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (i0 + 4 * tx + a < N) o[a] = r[a];
+        }
+    }
+}
+
 // k smallest of each row of dist, ascending, ties to the smaller index.  Two stages:
 //   stage 1: grid (chunks, Q): a workgroup keeps its chunk of 2 048 distances in registers (8 per
 //            thread) and extracts the chunk's k smallest by k rounds of (thread-local min, LDS reduce);
@@ -131,19 +312,24 @@ template <int PERT>
 __device__ __forceinline__ void select_k(float (&v)[PERT], int (&id)[PERT], int k, float *sv, int *si,
                                          float *out_v, int *out_i)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int r = 0; r < k; ++r) {
         float bv = INFINITY; int bi = 0x7fffffff, bs = -1;
 #pragma unroll
         for (int u = 0; u < PERT; ++u)
             if (lex_less(v[u], id[u], bv, bi)) { bv = v[u]; bi = id[u]; bs = u; }
-        sv[tid] = bv; si[tid] = bi;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o && lex_less(sv[tid + o], si[tid + o], sv[tid], si[tid])) { sv[tid] = sv[tid + o]; si[tid] = si[tid + o]; }
-            __syncthreads();
+        float wv = bv; int wi = bi;                          // wave argmin in registers, then 4 candidates in LDS
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(wv, o); const int oi = __shfl_xor(wi, o);
+            if (lex_less(ov, oi, wv, wi)) { wv = ov; wi = oi; }
         }
-        const float wv = sv[0]; const int wi = si[0];
+        if (lane == 0) { sv[wave] = wv; si[wave] = wi; }
+        __syncthreads();
+        wv = sv[0]; wi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (lex_less(sv[w], si[w], wv, wi)) { wv = sv[w]; wi = si[w]; }
         if (tid == 0) { out_v[r] = wv; out_i[r] = wi; }
         if (bs >= 0 && bi == wi && bv == wv) {              // the winning thread retires its element
 #pragma unroll
@@ -398,6 +584,32 @@ int nsc_w1_distances(const float *db, int32_t N, int32_t D, float eps, const flo
     case 8: hipLaunchKernelGGL(w1_dist_kernel<8>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
     case 12: hipLaunchKernelGGL(w1_dist_kernel<12>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
     default: hipLaunchKernelGGL(w1_dist_kernel<16>, grid, block, 0, st, db, N, D, eps, q_cdf, Q, db_pos, q_pos, min_dist, dist); break;
+    }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_w1_distances_cdf(const float *db_cdf, int32_t N, int32_t D, const float *q_cdf, int32_t Q,
+                         const float *db_pos, const float *q_pos, float min_dist, float *dist, void *stream_)
+{
+    if (N < 0 || Q < 0 || D < 4 || D > 1024 || (D & 3)) return NSC_EUNSUPPORTED;
+    if (N == 0 || Q == 0) return NSC_OK;
+    if (!db_cdf || !q_cdf || !dist) return NSC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(db_cdf) | reinterpret_cast<uintptr_t>(q_cdf)) & 15u) return NSC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (Q <= 4) {
+        int wgs = (N + 3) / 4;
+        if (wgs > 256 * 8) wgs = 256 * 8;                      // 8 resident workgroups per CU walk the rows
+        const dim3 grid(wgs), block(256);
+        if (Q == 1) hipLaunchKernelGGL(w1_stream_kernel<1>, grid, block, 0, st, db_cdf, N, D, q_cdf, Q, db_pos, q_pos, min_dist, dist);
+        else if (Q == 2) hipLaunchKernelGGL(w1_stream_kernel<2>, grid, block, 0, st, db_cdf, N, D, q_cdf, Q, db_pos, q_pos, min_dist, dist);
+        else hipLaunchKernelGGL(w1_stream_kernel<4>, grid, block, 0, st, db_cdf, N, D, q_cdf, Q, db_pos, q_pos, min_dist, dist);
+    } else {
+        // tile of 64 rows x 16 / 32 / 64 queries: the smallest one that covers Q in as few column tiles as 64 does
+        const int nq = Q <= 16 ? 1 : (Q <= 32 || (Q > 64 && Q <= 96) ? 2 : 4);
+        const dim3 grid((N + TL_I - 1) / TL_I, (Q + 16 * nq - 1) / (16 * nq)), block(256);
+        if (nq == 1) hipLaunchKernelGGL(w1_tile_kernel<1>, grid, block, 0, st, db_cdf, N, D, q_cdf, Q, db_pos, q_pos, min_dist, dist);
+        else if (nq == 2) hipLaunchKernelGGL(w1_tile_kernel<2>, grid, block, 0, st, db_cdf, N, D, q_cdf, Q, db_pos, q_pos, min_dist, dist);
+        else hipLaunchKernelGGL(w1_tile_kernel<4>, grid, block, 0, st, db_cdf, N, D, q_cdf, Q, db_pos, q_pos, min_dist, dist);
     }
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }

@@ -47,6 +47,19 @@ def _distances(db: torch.Tensor, qcdf: torch.Tensor, eps: float, db_pos=None, q_
     return dist
 
 
+def _distances_cdf(db_cdf: torch.Tensor, qcdf: torch.Tensor, db_pos=None, q_pos=None,
+                   min_dist: float = 0.0) -> torch.Tensor:
+    """W1 of query CDFs against rows that are already CDFs (nsc_w1_distances_cdf)."""
+    n, d, q = int(db_cdf.shape[0]), int(db_cdf.shape[1]), int(qcdf.shape[0])
+    dist = torch.empty((q, n), dtype=torch.float32, device=db_cdf.device)
+    with torch.cuda.device(db_cdf.device):
+        st = _lib.lib().nsc_w1_distances_cdf(_lib.ptr(db_cdf), n, d, _lib.ptr(qcdf), q, _lib.ptr(db_pos),
+                                             _lib.ptr(q_pos), float(min_dist), _lib.ptr(dist),
+                                             _lib.stream_ptr(db_cdf.device))
+    _lib.check(st, "nsc_w1_distances_cdf")
+    return dist
+
+
 def _topk(dist: torch.Tensor, k: int):
     q, n = int(dist.shape[0]), int(dist.shape[1])
     idx = torch.empty((q, k), dtype=torch.int64, device=dist.device)
@@ -87,6 +100,7 @@ class WassersteinRetriever:
         if self.device.type != "cuda":
             raise _lib.NscError("WassersteinRetriever keeps its database in HBM: device must be a HIP device")
         self._buf = None
+        self._cdf_buf = None       # normalised CDF of every database row (only when n_bins % 4 == 0)
         self._pos = None
         self.database_size = 0
 
@@ -105,12 +119,18 @@ class WassersteinRetriever:
         if self._buf is None or need > self._buf.shape[0]:
             cap = max(need, 2 * (0 if self._buf is None else self._buf.shape[0]), 1024)
             nb = torch.empty((cap, d), dtype=torch.float32, device=self.device)
+            nc = torch.empty((cap, d), dtype=torch.float32, device=self.device) if d % 4 == 0 else None
             npos = torch.zeros((cap, 3), dtype=torch.float32, device=self.device)
             if self._buf is not None:
                 nb[:self.database_size] = self._buf[:self.database_size]
                 npos[:self.database_size] = self._pos[:self.database_size]
-            self._buf, self._pos = nb, npos
+                if nc is not None:
+                    nc[:self.database_size] = self._cdf_buf[:self.database_size]
+            self._buf, self._pos, self._cdf_buf = nb, npos, nc
         self._buf[self.database_size:need] = h
+        if self._cdf_buf is not None:
+            # the database form of the normalisation (wasserstein.py:158-163), done once per inserted row
+            self._cdf_buf[self.database_size:need] = _cdf(h, 1e-8, False)
         if positions is not None:
             self._pos[self.database_size:need] = torch.as_tensor(np.asarray(positions), dtype=torch.float32).to(self.device)
         self.database_size = need
@@ -130,7 +150,10 @@ class WassersteinRetriever:
         if query_positions is not None:
             qp = torch.as_tensor(np.asarray(query_positions), dtype=torch.float32).to(self.device).reshape(-1, 3).contiguous()
             dbp = self._pos[:self.database_size]
-        dist = _distances(db, _cdf(q, 1e-8, True), 1e-8, dbp, qp, min_distance)
+        if self._cdf_buf is not None:
+            dist = _distances_cdf(self._cdf_buf[:self.database_size], _cdf(q, 1e-8, True), dbp, qp, min_distance)
+        else:
+            dist = _distances(db, _cdf(q, 1e-8, True), 1e-8, dbp, qp, min_distance)
         return _topk(dist, min(top_k, self.database_size))
 
     def query(self, query_hist: Union[np.ndarray, torch.Tensor], top_k: int = 10) -> tuple:
@@ -142,5 +165,5 @@ class WassersteinRetriever:
 
     def clear_database(self):
         """:386-389"""
-        self._buf = self._pos = None
+        self._buf = self._pos = self._cdf_buf = None
         self.database_size = 0

@@ -71,3 +71,37 @@ def test_gpu_batched_queries_with_spatial_filter():
     r2.add_to_database(same)
     i2, v2 = r2.query(db[0], top_k=4)
     assert i2.tolist() == [0, 1, 2, 3] and np.all(np.diff(v2) >= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,dim", [(300, 1, 800), (301, 2, 800), (1000, 3, 800), (1000, 4, 800), (130, 5, 800),
+                                      (1037, 64, 800), (2111, 97, 800), (513, 130, 52), (700, 9, 1024), (64, 7, 8),
+                                      (900, 20, 800), (400, 80, 800), (333, 16, 800), (257, 33, 800)])
+def test_gpu_cached_cdf_kernels(n, nq, dim):
+    """WassersteinRetriever keeps CDF rows: Q <= 4 takes the HBM-streaming kernel, Q > 4 the register-tiled one.
+    Distances against the numpy oracle, top-k identical (value order; ties by index), with the spatial filter."""
+    from neural_spectral_codec_amd.retrieval import WassersteinRetriever
+    rng = np.random.default_rng(n + nq)
+    db = (rng.random((n, dim)) ** 3).astype(np.float32)
+    db[5] = 0.0                                                       # empty histogram: stays unnormalised
+    pos = np.cumsum(rng.normal(0, 1.0, (n, 3)), 0).astype(np.float32)
+    q = (rng.random((nq, dim)) ** 3).astype(np.float32)
+    qpos = pos[rng.integers(0, n, nq)]
+    r = WassersteinRetriever(device="cuda")
+    r.add_to_database(db[: n // 3], positions=pos[: n // 3])          # grows the buffers (CDF cache follows)
+    r.add_to_database(db[n // 3:], positions=pos[n // 3:])
+    k = min(7, n)
+    for filt in (False, True):
+        idx, val = r.query_batch(q, top_k=k, query_positions=qpos if filt else None, min_distance=6.0)
+        idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        for j in range(nq):
+            d = ro.batch(q[j], db)
+            if filt:
+                d[np.linalg.norm(pos - qpos[j], axis=1) < 6.0] = np.inf
+            o, dv = ro.topk(d, k)
+            fin = np.isfinite(dv)
+            assert np.allclose(val[j][fin], dv[fin], rtol=RTOL, atol=1e-5), (j, filt)
+            assert np.isinf(val[j][~fin]).all()
+            # same set up to near-ties at the float32 summation-order level
+            close = np.abs(d[idx[j][fin]] - dv[fin]) <= RTOL * np.abs(dv[fin]) + 1e-5
+            assert close.all(), (j, filt)

@@ -19,7 +19,7 @@ def masked_stream(mask_bits):
     assert r == 0, r
     return torch.cuda.ExternalStream(s.value)
 
-n, npts = 1024, 120000
+n, npts = int(os.environ.get('NSC_PROBE_CLOUDS', '1024')), 120000
 enc = SpectralEncoder(n_elevation=16).to("cuda")
 pts, off = synth.make_clouds_device(n, npts, "cuda")
 outs = [torch.empty((n, 800), device="cuda") for _ in range(2)]

@@ -7,7 +7,7 @@ n = 100000
 r = WassersteinRetriever(device="cuda")
 db = torch.rand((n, 800), device="cuda") ** 3
 r.add_to_database(db)
-for q in (1, 16, 128):
+for q in (1, 4, 16, 32, 128):
     qs = db[:q].clone()
     for _ in range(3): r.query_batch(qs, 10)
     torch.cuda.synchronize()

@@ -14,6 +14,7 @@ For N > 1 the driver launches this file under torch.distributed.run (one rank pe
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -188,6 +189,8 @@ def main():
         sync()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(args.steps)]
+        gc.collect()
+        gc.disable()                                        # no collector pause on the enqueueing thread while timing
         t0 = time.perf_counter()
         for k in range(args.steps):
             # the encoder kernel is bracketed by HIP events on the stream it is launched on -> live per-launch
@@ -197,6 +200,7 @@ def main():
         t_issue = time.perf_counter() - t0                  # host side only: all K steps enqueued
         sync()
         dt = time.perf_counter() - t0
+        gc.enable()
         if chosen == "pipelined":
             desc_local = desc_all[rank * n_local:(rank + 1) * n_local] if world > 1 else desc_all
         # outside the timed region: the same kernel alone on the device (no GNN co-running), for reference

@@ -41,7 +41,6 @@ struct EncDev {
     float eps;
     int interp;
     int dev_skip_finish;   // development knob (NSC_TUNE_SKIP_FINISH): time the scatter phase alone
-    int dev_stagger_us;    // start-time stagger between the workgroups sharing a CU (microseconds)
 };
 
 // exp(-2 pi i j / 360) = (cos, -sin): table holds (cos, sin)
@@ -381,12 +380,6 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// everything after the image exists in LDS
-//   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
-//   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
-//   mode 2: img holds float32 range images from the caller -> interpolate + row copy only
-//           (interpolate_range_image(), range_image.py:15-89), result to out_interp
-// ---------------------------------------------------------------------------------------------
 // Twiddles and histogram segments -> LDS, by `nthr` cooperating threads (index t).  In the fused
 // kernel one wave does this while the others already stream points, so none of its global-load
 // latency is exposed.  The LUT is monotone: bin b owns frequencies [seg[b], seg[B+b]) with
@@ -409,43 +402,7 @@ __device__ __forceinline__ void setup_tables(unsigned char *lds, const EncDev &d
     }
 }
 
-// everything after the image exists in LDS
-//   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
-//   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
-//   mode 2: img holds float32 range images from the caller -> interpolate + row copy only
-//           (interpolate_range_image(), range_image.py:15-89), result to out_interp
 // ---------------------------------------------------------------------------------------------
-// Twiddles and histogram segments -> LDS.  Called at kernel start (before the point stream in the
-// fused kernel) so none of its global-load latency sits in the finish phase.  The LUT is monotone:
-// bin b owns frequencies [seg[b], seg[B+b]); bins no frequency maps to keep the empty segment [0,0).
-// The caller must __syncthreads() before finish_image().
-template <int NW>
-__device__ __forceinline__ void setup_tables(unsigned char *lds, const EncDev &d, const int *__restrict__ lut)
-{
-    constexpr int NT = NW * 64;
-    const int tid = threadIdx.x;
-    const LdsPlan lp = lds_plan(d.E, d.R, d.B, NW);
-    double2 *tw = reinterpret_cast<double2 *>(lds + lp.tw);
-    int *seg = reinterpret_cast<int *>(lds + lp.seg);
-    const int B = d.B;
-    for (int i = tid; i < TW_N; i += NT) tw[i] = g_tw360[i];
-    // each thread k < 181 compares lut[k] with its neighbours (3 cached loads, no LDS hand-off)
-    for (int b = tid; b < 2 * B; b += NT) {
-        // bins without frequencies: written first by the owner thread of the slot, segment starts
-        // below overwrite slots of non-empty bins only -> no race (a slot has exactly one writer:
-        // either this initialiser if the bin is empty, or the boundary thread if it is not)
-        int lo = 0;
-        const int bb = b < B ? b : b - B;
-        bool found = false;
-        // monotone LUT: binary search for the first k with lut[k] >= bb (+1 for the end)
-        int l = 0, h = F;
-        const int key = (b < B) ? bb : bb + 1;
-        while (l < h) { const int m = (l + h) >> 1; if (lut[m] >= key) h = m; else l = m + 1; }
-        lo = l; (void)found;
-        seg[b] = lo;                       // start of bin bb (b < B) or start of bin bb+1 = end of bin bb
-    }
-}
-
 // everything after the image exists in LDS
 //   mode 0: img holds squared-range bits (scatter output)  -> sqrt, interpolate, row copy
 //   mode 1: img holds float32 range images from the caller -> no interpolation (forward(), :231)
@@ -595,18 +552,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void encode_fused_kernel(
     unsigned *img = reinterpret_cast<unsigned *>(lds);
     const int npix = d.E * A;
     for (int i = tid; i < npix; i += NT) img[i] = NSC_EMPTY_BITS;  // :205 full(inf)
-    if (d.dev_stagger_us > 0) {
-        // Desynchronise the workgroups that share a CU (observed placement: consecutive groups of
-        // 256 blocks fill one slot per CU): a later slot starts its point stream a little later, so
-        // its finish phase overlaps the other slots' streaming instead of idling HBM.  Speed only:
-        // any placement gives the same results.
-        const int slot = blockIdx.x >> 8;
-        if (slot > 0 && slot < 8) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-            const unsigned long long wait = (unsigned long long)d.dev_stagger_us * 100ull * slot;
-            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     __syncthreads();
     if (tid >= NT - 64) setup_tables<NW>(lds, d, lut, tid - (NT - 64), 64);   // last wave; joins the stream late
     scatter_range<NT, U>(pts, off[c], off[c + 1], stride, tid, d.bp, img, d.dev_skip_finish & 32);
@@ -750,7 +695,6 @@ EncDev make_dev(const NscEncParams *p, int rows_in)
     d.eps = p->epsilon;
     d.interp = p->interpolate;
     d.dev_skip_finish = tune_env("NSC_TUNE_SKIP_FINISH", 0);
-    d.dev_stagger_us = tune_env("NSC_TUNE_STAGGER_US", 0);
     return d;
 }
 

@@ -30,11 +30,6 @@ for v in variants:
     os.environ.pop("NSC_TUNE_SKIP_FINISH")
     print(f"variant {v}: {us:.1f} us  {gb/us*1e6:.0f} GB/s   scatter-only {us2:.1f} us {gb/us2*1e6:.0f} GB/s   loads-only {us3:.1f} us {gb/us3*1e6:.0f} GB/s", flush=True)
 os.environ["NSC_TUNE_VARIANT"] = "0"
-for st in (0, 2, 4, 6, 8, 12, 16):
-    os.environ["NSC_TUNE_STAGGER_US"] = str(st)
-    us = timeit(lambda: enc.encode_points_batch((pts, off), out=out), reps=20)
-    print(f"stagger {st} us: {us:.1f} us  {gb/us*1e6:.0f} GB/s", flush=True)
-os.environ.pop("NSC_TUNE_STAGGER_US")
 for parts in (2, 4):
     os.environ["NSC_TUNE_SPLIT"] = str(parts)
     us = timeit(lambda: enc.encode_points_batch((pts, off), out=out))

@@ -296,3 +296,21 @@ def test_voxel_overlap_gpu_properties():
         pu.compute_overlap(big, big, eye, max_points=7000)            # 14 000 points > hash-set capacity
     with pytest.raises(Exception):
         pu.compute_overlap(p, p, eye, voxel_size=0.0)
+
+
+@pytest.mark.gpu
+def test_empty_inputs():
+    """n = 0 everywhere: nothing is launched, shapes are kept."""
+    from neural_spectral_codec_amd.data import pose_utils as pu
+    from neural_spectral_codec_amd.encoding import quantization as qz
+    from neural_spectral_codec_amd.keyframe.graph_manager import build_chain_graph
+    q = qz.quantize_batch(torch.empty((0, 800), device="cuda"))
+    assert tuple(q.shape) == (0, 800) and q.dtype == torch.uint16
+    assert tuple(qz.dequantize_batch(q).shape) == (0, 800)
+    rec = qz.pack_records(q, torch.empty((0, 7)), torch.empty((0,), dtype=torch.float64),
+                          torch.empty((0,), dtype=torch.int64), torch.empty((0, 20), dtype=torch.uint8))
+    assert tuple(rec.shape) == (0, 1720)
+    g = build_chain_graph(torch.zeros((0, 800)), 5, "cuda", np.zeros((0, 4, 4)))
+    assert tuple(g.edge_index.shape) == (2, 0)
+    iou = pu.compute_overlap_batch([], [], np.zeros((0, 4, 4)))
+    assert tuple(iou.shape) == (0,)

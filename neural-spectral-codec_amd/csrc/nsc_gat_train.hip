@@ -197,10 +197,18 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__re
                                                               float *__restrict__ out_a, float *__restrict__ out_b,
                                                               float *__restrict__ run_mean, float *__restrict__ run_var)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // 64 columns per workgroup, the R partial rows split over the 4 waves (fixed order -> deterministic)
+    __shared__ double sa[256], sb[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     double a = 0.0, b = 0.0;
-    for (int r = 0; r < R; ++r) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
+    if (c < C)
+        for (int r = ry; r < R; r += 4) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    if (ry != 0 || c >= C) return;
+    a = (sa[cx] + sa[64 + cx]) + (sa[128 + cx] + sa[192 + cx]);
+    b = (sb[cx] + sb[64 + cx]) + (sb[128 + cx] + sb[192 + cx]);
     if (mode == 0) {
         if (out_a) out_a[c] = (float)a;
         if (out_b) out_b[c] = (float)b;
@@ -462,30 +470,52 @@ __global__ __launch_bounds__(256) void att_bwd_source_kernel(AttBwdB a)
     if (lane == 0) a.da_src[j] = das;
 }
 
-// dv[d] = sum_e draw[e] * ea_e[d]  (edge term gradient), single workgroup, deterministic
+// dv[d] = sum_e draw[e] * ea_e[d]  (edge term gradient): EDGE_BWD_WGS workgroups write float64 partials, a second
+// tiny kernel adds them in workgroup order -> deterministic
+constexpr int EDGE_BWD_WGS = 64;
+
 __global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restrict__ row_ptr,
                                                             const int *__restrict__ eid,
                                                             const int *__restrict__ tgt,
                                                             const float *__restrict__ loop_attr,
                                                             const float *__restrict__ edge_attr,
                                                             const float *__restrict__ draw, int N, int edge_dim,
-                                                            float *__restrict__ dv)
+                                                            double *__restrict__ part)
 {
     __shared__ double sh[256];
     const int nnz = row_ptr[N];
-    for (int d = 0; d < edge_dim; ++d) {
-        double s = 0.0;
-        for (int e = threadIdx.x; e < nnz; e += 256) {
-            const int id = eid[e];
-            const float ea = id >= 0 ? edge_attr[(long long)id * edge_dim + d]
-                                     : loop_attr[(long long)tgt[e] * edge_dim + d];
-            s += (double)draw[e] * (double)ea;
-        }
-        sh[threadIdx.x] = s;
+    double s[NSC_GAT_MAX_EDGE_DIM];
+#pragma unroll
+    for (int d = 0; d < NSC_GAT_MAX_EDGE_DIM; ++d) s[d] = 0.0;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nnz; e += gridDim.x * 256) {
+        const int id = eid[e];
+        const float *ea = id >= 0 ? edge_attr + (long long)id * edge_dim : loop_attr + (long long)tgt[e] * edge_dim;
+        const double dr = (double)draw[e];
+#pragma unroll
+        for (int d = 0; d < NSC_GAT_MAX_EDGE_DIM; ++d)
+            if (d < edge_dim) s[d] += dr * (double)ea[d];
+    }
+#pragma unroll
+    for (int d = 0; d < NSC_GAT_MAX_EDGE_DIM; ++d) {
+        if (d >= edge_dim) break;
+        sh[threadIdx.x] = s[d];
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-        if (threadIdx.x == 0) dv[d] = (float)sh[0];
+        if (threadIdx.x == 0) part[blockIdx.x * NSC_GAT_MAX_EDGE_DIM + d] = sh[0];
         __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void edge_term_bwd_final_kernel(const double *__restrict__ part, int nparts,
+                                                                 int edge_dim, float *__restrict__ dv)
+{
+    // lane g holds partial g (nparts <= 64); fixed shuffle tree -> deterministic
+    const int lane = threadIdx.x;
+    for (int d = 0; d < edge_dim; ++d) {
+        double s = lane < nparts ? part[lane * NSC_GAT_MAX_EDGE_DIM + d] : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) dv[d] = (float)s;
     }
 }
 
@@ -493,11 +523,14 @@ __global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restric
 __global__ __launch_bounds__(256) void edge_vec_kernel(const float *__restrict__ w_edge, const float *__restrict__ att_edge,
                                                        int H, int edge_dim, float *__restrict__ v)
 {
-    const int d = threadIdx.x;
-    if (d >= edge_dim) return;
-    float s = 0.0f;
-    for (int c = 0; c < H; ++c) s = __builtin_fmaf(w_edge[(long long)c * edge_dim + d], att_edge[c], s);
-    v[d] = s;
+    // one wavefront per component d: lane-strided partial dot products, then the xor-shuffle tree
+    const int lane = threadIdx.x & 63;
+    for (int d = threadIdx.x >> 6; d < edge_dim; d += 4) {
+        float s = 0.0f;
+        for (int c = lane; c < H; c += 64) s = __builtin_fmaf(w_edge[(long long)c * edge_dim + d], att_edge[c], s);
+        s = wave_sumf(s);
+        if (lane == 0) v[d] = s;
+    }
 }
 __global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const float *__restrict__ w_edge, const float *__restrict__ att_edge,
                                                            const float *__restrict__ dv, int H, int edge_dim,
@@ -684,7 +717,7 @@ void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, c
     if (R < 1) R = 1;
     const int rows = (N + R - 1) / R;
     hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part);
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, R, C, mode, N, eps, momentum,
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, mode, N, eps, momentum,
                        out_a, out_b, run_mean, run_var);
 }
 
@@ -864,8 +897,10 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr);
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
             if (use_edge) {
-                hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(1), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt, g->loop_attr,
-                                   edge_attr, F(w.draw), N, m->edge_dim, F(w.dvvec));
+                hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,
+                                   g->loop_attr, edge_attr, F(w.draw), N, m->edge_dim, colpart);
+                hipLaunchKernelGGL(edge_term_bwd_final_kernel, dim3(1), dim3(64), 0, st, colpart, EDGE_BWD_WGS, m->edge_dim,
+                                   F(w.dvvec));
                 hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(blocks(H)), dim3(256), 0, st, Ly.lin_edge_w, Ly.att_edge, F(w.dvvec),
                                    H, m->edge_dim, Gl.lin_edge_w, Gl.att_edge);
             } else {

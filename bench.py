@@ -161,7 +161,7 @@ def main():
         for name in paths:                                  # the first step also builds the cached graph
             use(name)
             for _ in range(max(SPINUP_STEPS - args.warmup, 1)):
-                path.step((pts, off))
+                path.step((pts, off), inputs_ready=True)
             sync()
         if args.serial or args.pipelined:
             use("serial" if args.serial else "pipelined")
@@ -173,7 +173,7 @@ def main():
                     sync()
                     tc = time.perf_counter()
                     for _ in range(CALIB_STEPS):
-                        path.step((pts, off))
+                        path.step((pts, off), inputs_ready=True)
                     sync()
                     calib[name] = min(calib.get(name, 1e9), (time.perf_counter() - tc) / CALIB_STEPS)
             tcal = torch.tensor([calib["pipelined"], calib["serial"]], dtype=torch.float64, device=dev)
@@ -185,7 +185,7 @@ def main():
         chosen = "pipelined" if path is paths["pipelined"] else "serial"
         sync()
         for _ in range(args.warmup):                        # the W untimed warmup steps of the contract
-            path.step((pts, off))
+            path.step((pts, off), inputs_ready=True)
         sync()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(args.steps)]
@@ -196,7 +196,7 @@ def main():
             # the encoder kernel is bracketed by HIP events on the stream it is launched on -> live per-launch
             # duration for the roofline object.  Every EV_EVERY-th launch is bracketed: a timing-event pair
             # costs ~7 us of idle between two back-to-back encoder launches of the pipelined path.
-            desc_all, emb = path.step((pts, off), encoder_events=ev[k] if k % EV_EVERY == 0 else None)
+            desc_all, emb = path.step((pts, off), encoder_events=ev[k] if k % EV_EVERY == 0 else None, inputs_ready=True)
         t_issue = time.perf_counter() - t0                  # host side only: all K steps enqueued
         sync()
         dt = time.perf_counter() - t0

@@ -156,13 +156,16 @@ class ShardedDescriptorPath:
         self._ev_enc = [torch.cuda.Event() for _ in range(nb)]
         self._ev_gnn = [torch.cuda.Event() for _ in range(nb)]
 
-    def _step_pipelined(self, clouds, encoder_events):
+    def _step_pipelined(self, clouds, encoder_events, inputs_ready):
         device = self.encoder.alpha.device
         if self._streams is None:
             self._pipe_setup(device)
         sE, sG = self._streams
         nb = self._PIPE_BUFFERS
         i = self._k % nb
+        if not inputs_ready:
+            # the clouds may still be being written on the caller's stream: order the encoder behind it
+            sE.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(sE):
             # batch k-nb must have been read out of this buffer.  With nb buffers in rotation that GNN pass
             # has normally finished long ago: ask the host first, so that the encoder stream carries no
@@ -189,12 +192,15 @@ class ShardedDescriptorPath:
             cur.wait_stream(self._streams[0])
             cur.wait_stream(self._streams[1])
 
-    def step(self, clouds, encoder_events=None):
+    def step(self, clouds, encoder_events=None, inputs_ready: bool = False):
         """clouds: this rank's shard (list of arrays or (points, offsets) device tensors).
         Returns (all descriptors (n_total, D), enhanced embeddings of the owned rows (hi-lo, D)).
-        ``encoder_events``: optional (start, end) torch.cuda.Event pair recorded around the encoder launch."""
+        ``encoder_events``: optional (start, end) torch.cuda.Event pair recorded around the encoder launch.
+        ``inputs_ready`` (pipeline mode): the clouds are already complete in HBM (nothing pending on the caller's
+        stream writes them), so the encoder stream does not have to wait for the caller's stream -- that
+        cross-stream wait costs ~10 us of idle between two encoder launches."""
         if self.pipeline:
-            return self._step_pipelined(clouds, encoder_events)
+            return self._step_pipelined(clouds, encoder_events, inputs_ready)
         if encoder_events is not None:
             encoder_events[0].record()
         local = self.encoder.encode_points_batch(clouds)

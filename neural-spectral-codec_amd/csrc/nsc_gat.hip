@@ -15,8 +15,10 @@
 //   gat_aggregate_kernel one wavefront per target node: leaky-relu logits, wave-shuffle softmax over the
 //                        node's in-edges, alpha-weighted sum of neighbour rows (float4 per lane), fused
 //                        bias + BatchNorm(eval) + ReLU + residual epilogue
+//   gemm_nt_direct_kernel / gat_aggregate_kernel<1,4,false>
+//                        the NSC_GAT_CORESIDENT set: no LDS, < 64 VGPRs, bit-identical output -- fits beside a
+//                        resident encoder grid so that the GNN of batch k runs under the encoder of batch k+1
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 
 #include "../../include/nsc.h"
 

@@ -20,7 +20,25 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ncl = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 npts = int(sys.argv[3]) if len(sys.argv) > 3 else 120000
 threads = min(os.cpu_count() or 1, 128)
-enc = SpectralEncoder(n_elevation=16).to("cuda")
+# parameter sets: the path's shape, the 64-row projector pooled to 16 rows, the float32 row chain of numpy 1.24,
+# a wide FOV (no narrow-FOV shortcut), another alpha / bin count, (N,3) input
+CFG = [dict(),
+       dict(n_elevation=64, target_elevation_bins=16),
+       dict(elev_float64=False),
+       dict(elevation_range=(-40.0, 35.0)),
+       dict(n_bins=37, alpha=1.3),
+       dict(xyz_only=True)]
+cfg_id = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+kw = dict(CFG[cfg_id])
+xyz_only = kw.pop("xyz_only", False)
+kw.setdefault("n_elevation", 16)
+enc = SpectralEncoder(**kw).to("cuda")
+op = nsc_oracle.default_params(n_elevation=enc.n_elevation, target_rows=enc.target_elevation_bins, n_bins=enc.n_bins,
+                               elev_f64=int(kw.get("elev_float64", True)))
+if "elevation_range" in kw:
+    op.elev_min_rad, op.elev_max_rad = np.deg2rad(kw["elevation_range"][0]), np.deg2rad(kw["elevation_range"][1])
+olut = nsc_oracle.bin_lut(float(kw.get("alpha", 2.0)), enc.n_bins, 181, 1e-8)[1]
+print("config", cfg_id, CFG[cfg_id], flush=True)
 tot_pts = bad_raw = bad_itp = 0
 worst = 0.0
 t0 = time.time()
@@ -33,9 +51,11 @@ for rd in range(rounds):
         pts[idx, 0] = float("inf")
     if rd % 3 == 2:                                   # sparse rows: squeeze elevation so that rows stay empty
         pts[:, 2] *= 0.2
+    if xyz_only:
+        pts = pts[:, :3].contiguous()
     desc, raw, itp = enc.encode_points_batch((pts, off), return_images=True)
     hp, ho = pts.cpu().numpy(), off.cpu().numpy()
-    od, oraw, oitp = nsc_oracle.encode_clouds(hp, ho, n_threads=threads, want_images=True)
+    od, oraw, oitp = nsc_oracle.encode_clouds(hp, ho, p=op, lut=olut, n_threads=threads, want_images=True)
     raw, itp, desc = raw.cpu().numpy(), itp.cpu().numpy(), desc.cpu().numpy()
     bad_raw += int((raw.view(np.uint32) != oraw.view(np.uint32)).sum())
     bad_itp += int((itp.view(np.uint32) != oitp.view(np.uint32)).sum())

@@ -50,6 +50,18 @@ def test_argument_validation_without_gpu(lib):
     # split-path workspace: small batches of big clouds need E*360*4 bytes per cloud, big batches none
     assert lib.nsc_encode_clouds_workspace_bytes(4, 480000, p) == 4 * 16 * 360 * 4
     assert lib.nsc_encode_clouds_workspace_bytes(1024, 1024 * 120000, p) == 0
+    # the rows added around the path: shape checks answer without a device as well
+    assert lib.nsc_gat_forward_ex(None, None, None, None, None, None, None, 0, 2, None) == -1     # unknown flag
+    assert lib.nsc_quantize_descriptors(None, 0, 800, 1e-8, None, None) == 0
+    assert lib.nsc_quantize_descriptors(None, 3, 800, 1e-8, None, None) == -1
+    assert lib.nsc_quantize_descriptors(None, 3, 5000, 1e-8, None, None) in (-1, -2)
+    assert lib.nsc_record_bytes(50) == 220 and lib.nsc_record_bytes(800) == 1720
+    assert lib.nsc_chain_graph_num_edges(4541, 5, 0) == 18158                 # E = 4N - 6
+    assert lib.nsc_chain_graph_num_edges(3, 5, 2) == 6 + 4 and lib.nsc_chain_graph_num_edges(1, 5, 0) == 0
+    assert lib.nsc_voxel_overlap_workspace_bytes(5000, 5000) == 10000 * 16
+    assert lib.nsc_voxel_overlap(None, None, None, None, 1, 20000, 0, 20000, 3, None, 0.2, None, None, None, 0, None) == -1
+    assert lib.nsc_w1_distances_cdf(None, 10, 50, None, 1, None, None, 0.0, None, None) == -2        # dim % 4 != 0
+    assert lib.nsc_topk_workspace_bytes(1, 100000, 10) == 49 * 10 * 8
 
 
 def test_product_refuses_cpu_tensors():

@@ -100,6 +100,13 @@ int nsc_encode_range_images(const float *imgs, int32_t n_images, int32_t rows,
                             const NscEncParams *p, const int32_t *lut, float *out_desc,
                             void *stream);
 
+/* Intensity image of RangeImageProjector.project(points, keep_intensity=True) (reference range_image.py:216-228):
+ * per pixel the maximum intensity over the points whose float32 range equals the pixel's minimum range, 0 where no
+ * point fell (and never below 0: the reference max-reduces into a zero image).  points are (N,4) rows; range_raw is
+ * the raw range image batch of the same clouds (out_raw of nsc_encode_clouds).  Intensities that are NaN are ignored. */
+int nsc_project_intensity(const float *points, const int64_t *cloud_offsets, int32_t n_clouds, int64_t total_points,
+                          const NscEncParams *p, const float *range_raw, float *out_intensity, void *stream);
+
 /* interpolate_range_image(img, 'linear') (reference range_image.py:15-89) for a batch of float32 range
  * images (n_images, rows, 360), 0 = empty pixel; rows 1..64. */
 int nsc_interpolate_range_images(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,

@@ -92,6 +92,7 @@ SYMBOLS = {
     "nsc_enc_default_params": (None, [_pp]),
     "nsc_encode_clouds_workspace_bytes": (_sz, [_i32, _i64, _pp]),
     "nsc_encode_clouds": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_project_intensity": (C.c_int, [_vp, _vp, _i32, _i64, _pp, _vp, _vp, _vp]),
     "nsc_scatter_clouds": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _pp, _vp, _vp]),
     "nsc_finish_images": (C.c_int, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp]),
     "nsc_interpolate_range_images": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),

@@ -638,6 +638,34 @@ __global__ __launch_bounds__(NW * 64) void finish_kernel(
                      out_interp ? out_interp + (long long)c * npix : nullptr);
 }
 
+// Intensity image of RangeImageProjector.project(keep_intensity=True), range_image.py:216-228: per pixel the
+// MAXIMUM intensity over the points whose range equals the pixel's minimum range, starting from 0 (np.maximum.at
+// into a zero image).  `range` is the raw range image of the same cloud (sqrtf of the min squared range; sqrtf
+// is correctly rounded, so r == range[pix] is the reference's float32 comparison).  Positive floats order like
+// their bit patterns, so the maximum is an integer atomicMax; intensities <= 0 never raise the 0 the image
+// starts from, NaN intensities are ignored (numpy would propagate them).
+__global__ __launch_bounds__(256) void intensity_kernel(const float *__restrict__ pts, const long long *__restrict__ off,
+                                                        int parts, NscBinParams bp, int npix,
+                                                        const float *__restrict__ range, int *__restrict__ out)
+{
+    const int c = blockIdx.x / parts, part = blockIdx.x - c * parts;
+    const long long p0 = off[c], n = off[c + 1] - p0;
+    const long long chunk = (n + parts - 1) / parts;
+    const long long a = p0 + (long long)part * chunk;
+    long long b = a + chunk;
+    if (b > p0 + n) b = p0 + n;
+    const f32x4 *P = reinterpret_cast<const f32x4 *>(pts);
+    const float *rng = range + (long long)c * npix;
+    int *o = out + (long long)c * npix;
+    for (long long i = a + threadIdx.x; i < b; i += 256) {
+        const f32x4 v = P[i];
+        int pix; float s;
+        if (!nsc_point_pixel(v.x, v.y, v.z, bp, pix, s)) continue;
+        if (sqrtf(s) != rng[pix]) continue;
+        if (v.w > 0.0f) atomicMax(&o[pix], __float_as_int(v.w));
+    }
+}
+
 __global__ __launch_bounds__(256) void point_bins_kernel(
     const float *__restrict__ pts, long long n, int stride, NscBinParams bp,
     int *__restrict__ out_idx, unsigned char *__restrict__ out_flags)
@@ -811,6 +839,32 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
                            static_cast<const unsigned *>(ws), static_cast<const float *>(nullptr), 0, d, lut,
                            out_desc, out_raw, out_interp);
     }
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
+int nsc_project_intensity(const float *pts, const int64_t *cloud_offsets, int32_t n_clouds, int64_t total_points,
+                          const NscEncParams *p, const float *range_raw, float *out_intensity, void *stream_)
+{
+    int st = check_params(p);
+    if (st != NSC_OK) return st;
+    if (n_clouds < 0 || total_points < 0) return NSC_EINVAL;
+    if (n_clouds == 0) return NSC_OK;
+    if (!cloud_offsets || !range_raw || !out_intensity || (!pts && total_points > 0)) return NSC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(pts) & 15u) return NSC_EINVAL;                     // (N,4) rows, 16-byte loads
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const EncDev d = make_dev(p, p->n_elevation);
+    const int npix = d.E * A;
+    if (hipMemsetAsync(out_intensity, 0, (size_t)n_clouds * npix * sizeof(float), stream) != hipSuccess) return NSC_ELAUNCH;
+    int parts = 1;
+    if (n_clouds < 1024) {                       // fill the chip when the batch is small
+        const long long avg = total_points / n_clouds;
+        long long want = (2048 + n_clouds - 1) / n_clouds, by_size = avg / 4096;
+        parts = (int)(want < by_size ? want : by_size);
+        if (parts < 1) parts = 1;
+    }
+    hipLaunchKernelGGL(intensity_kernel, dim3((unsigned)(n_clouds * parts)), dim3(256), 0, stream, pts,
+                       reinterpret_cast<const long long *>(cloud_offsets), parts, d.bp, npix, range_raw,
+                       reinterpret_cast<int *>(out_intensity));
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

@@ -3,8 +3,8 @@
 Mirrors the hot-path surface of the reference's src/encoding/range_image.py:
 ``RangeImageProjector`` (:92-232) and ``interpolate_range_image`` (:15-89).  Both run inside the
 HIP encoder kernels (csrc/nsc_encoder.hip); these wrappers exist so callers that reach for
-``encoder.projector.project(...)`` keep working.  ``unproject``/visualisation helpers are not
-part of the path and are not provided.
+``encoder.projector.project(...)`` keep working (range image and, for (N,4) input, the intensity image
+of keep_intensity=True).  ``unproject``/visualisation helpers are not part of the path and are not provided.
 """
 from typing import Optional, Tuple
 
@@ -73,14 +73,23 @@ class RangeImageProjector:
 
     def project(self, points: np.ndarray, keep_intensity: bool = True
                 ) -> Tuple[np.ndarray, Optional[np.ndarray]]:
-        """range_image.py:129-232.  Returns (range_image (E,A) float32 ndarray, None)."""
-        if keep_intensity and np.asarray(points).shape[1] == 4:
-            raise NotImplementedError(
-                "intensity images are outside the MI355X descriptor path; call "
-                "project(points, keep_intensity=False) as SpectralEncoder.encode_points does "
-                "(reference spectral_encoder.py:217)")
-        raw, _ = self.project_images(points, interpolate=False)
-        return raw.cpu().numpy(), None
+        """range_image.py:129-232.  Returns (range_image, intensity_image) as (E,A) float32 ndarrays; the
+        intensity image is None for (N,3) input or keep_intensity=False, as in the reference."""
+        from .spectral_encoder import _run_encode_clouds, _default_lut
+        dev = self.device
+        t, stride = _as_points(points, dev)
+        n = int(t.shape[0])
+        off = torch.tensor([0, n], dtype=torch.int64, device=dev)
+        p = self._params(interpolate=False)
+        _, raw, _ = _run_encode_clouds(t, off, 1, n, stride, p, _default_lut(dev), want_images=True)
+        if not (keep_intensity and stride == 4):
+            return raw[0].cpu().numpy(), None
+        inten = torch.empty_like(raw)
+        with torch.cuda.device(dev):
+            st = _lib.lib().nsc_project_intensity(_lib.ptr(t), _lib.ptr(off), 1, n, p, _lib.ptr(raw), _lib.ptr(inten),
+                                                  _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_project_intensity")
+        return raw[0].cpu().numpy(), inten[0].cpu().numpy()
 
 
 def interpolate_range_image(range_image: np.ndarray, method: str = "linear",

@@ -105,6 +105,25 @@ def project(points, p=None, want_idx=False):
     return (img, idx, kept) if want_idx else img
 
 
+def project_intensity(points, p=None):
+    """range_image.py:216-228 on top of the C projection: (range image, intensity image).  The per-point range
+    r = sqrt(clip(x^2) + clip(y^2) + clip(z^2)) is recomputed with numpy float32 ops exactly as :159-162 writes it
+    (IEEE sqrt, no vendor math), the pixel index comes from nsc_oracle_project."""
+    p = p or default_params()
+    pts = _pts(points)
+    assert pts.shape[1] == 4
+    img, idx, _ = project(pts, p, want_idx=True)
+    keep = idx >= 0
+    x, y, z = pts[keep, 0], pts[keep, 1], pts[keep, 2]
+    r = np.sqrt(np.clip(x ** 2, 0, 1e10) + np.clip(y ** 2, 0, 1e10) + np.clip(z ** 2, 0, 1e10))   # :159-162
+    flat = img.reshape(-1)
+    li = idx[keep].astype(np.int64)
+    closest = r == flat[li]                                                                      # :222
+    out = np.zeros(flat.shape, dtype=np.float32)                                                 # :219
+    np.maximum.at(out, li[closest], pts[keep, 3][closest])                                       # :225
+    return img, out.reshape(img.shape)
+
+
 def interpolate(img):
     out = np.ascontiguousarray(img, dtype=np.float32).copy()
     lib().nsc_oracle_interpolate(_f(out), out.shape[0], out.shape[1])

@@ -237,3 +237,23 @@ def test_full_bench_size_properties():
     for c in (0, 511, 1023):
         host = pts[c * npts:(c + 1) * npts].cpu().numpy()
         assert _close(d[c].cpu().numpy(), orc.encode_points(host), 1e-6, 1e-9)
+
+
+def test_intensity_image_matches_reference():
+    """RangeImageProjector.project(points, keep_intensity=True): range and intensity images against the fixture made
+    by the reference itself (oracle/gen_golden_intensity.py) and against the oracle restatement."""
+    from neural_spectral_codec_amd.encoding.range_image import RangeImageProjector
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intensity.npz"))
+    proj = RangeImageProjector(n_elevation=16, n_azimuth=360, device="cuda")
+    for k in ("c0", "c1", "c2"):
+        pts = g[k + "_pts"]
+        rimg, iimg = proj.project(pts, keep_intensity=True)
+        assert rimg.dtype == np.float32 and iimg.dtype == np.float32 and iimg.shape == (16, 360)
+        assert (rimg.view(np.uint32) == g[k + "_range"].view(np.uint32)).all(), k
+        assert (iimg.view(np.uint32) == g[k + "_intensity"].view(np.uint32)).all(), k
+        oimg, ointen = orc.project_intensity(pts)
+        assert (iimg.view(np.uint32) == ointen.view(np.uint32)).all() and (rimg.view(np.uint32) == oimg.view(np.uint32)).all()
+    r2, i2 = proj.project(g["c0_pts"], keep_intensity=False)
+    assert i2 is None and (r2.view(np.uint32) == g["c0_range"].view(np.uint32)).all()
+    r3, i3 = proj.project(g["c0_pts"][:, :3])                       # (N,3): no intensity column
+    assert i3 is None and (r3.view(np.uint32) == g["c0_range"].view(np.uint32)).all()

@@ -112,3 +112,14 @@ def test_threads_agree():
     b = orc.encode_clouds(pts, off, n_threads=3)
     assert np.array_equal(a, b)
     assert np.array_equal(a[2], orc.encode_points(pts[off[2]:off[3]]))
+
+
+def test_intensity_oracle_matches_reference():
+    """nsc_oracle.project_intensity vs the reference's project(keep_intensity=True) (tests/golden/intensity.npz)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intensity.npz"))
+    for k in ("c0", "c1", "c2"):
+        img, inten = orc.project_intensity(g[k + "_pts"])
+        assert (img.view(np.uint32) == g[k + "_range"].view(np.uint32)).all(), k
+        assert (inten.view(np.uint32) == g[k + "_intensity"].view(np.uint32)).all(), k
+        assert inten.min() >= 0.0 and (inten > 0).sum() > 1000

@@ -92,6 +92,13 @@ class RangeImageProjector:
         return raw[0].cpu().numpy(), inten[0].cpu().numpy()
 
 
+def project_to_range_image(points: np.ndarray, n_elevation: int = 64, n_azimuth: int = 360,
+                           device="cuda") -> np.ndarray:
+    """Convenience wrapper of range_image.py:302-323: (N,3|4) points -> (n_elevation, n_azimuth) range image."""
+    return RangeImageProjector(n_elevation=n_elevation, n_azimuth=n_azimuth, device=device).project(
+        points, keep_intensity=False)[0]
+
+
 def interpolate_range_image(range_image: np.ndarray, method: str = "linear",
                             device="cuda") -> np.ndarray:
     """range_image.py:15-89 (method='linear') on the device: (rows, 360) image with 0 for empty pixels

@@ -257,3 +257,6 @@ def test_intensity_image_matches_reference():
     assert i2 is None and (r2.view(np.uint32) == g["c0_range"].view(np.uint32)).all()
     r3, i3 = proj.project(g["c0_pts"][:, :3])                       # (N,3): no intensity column
     assert i3 is None and (r3.view(np.uint32) == g["c0_range"].view(np.uint32)).all()
+    from neural_spectral_codec_amd.encoding.range_image import project_to_range_image
+    r4 = project_to_range_image(g["c0_pts"], n_elevation=16)
+    assert (r4.view(np.uint32) == g["c0_range"].view(np.uint32)).all()

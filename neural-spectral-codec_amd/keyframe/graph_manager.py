@@ -142,6 +142,12 @@ def build_graph_from_keyframes_batch(keyframes, temporal_neighbors: int = 5, dev
     return build_chain_graph(feats, temporal_neighbors, device, poses, loop_closures)
 
 
+def build_graph_from_keyframes(keyframes, temporal_neighbors: int = 5, device: str = 'cpu'):
+    """graph_manager.py:443-470: the graph TemporalGraphManager builds when every keyframe is active -- the same
+    chain edges in the same order (:130-165), no edge_attr."""
+    return build_graph_from_keyframes_batch(keyframes, temporal_neighbors, device, poses=None)
+
+
 def synthetic_chain_graph(n_nodes: int, device="cpu", seed: int = 0, temporal_neighbors: int = 5,
                           features: Optional[torch.Tensor] = None):
     """KITTI-00-shaped synthetic graph: positive rows summing to 1

@@ -85,6 +85,17 @@ def test_host_graph_builder_matches_literal_loop():
             assert np.abs(g.edge_attr.numpy() - ea).max() <= 2e-7
 
 
+def test_build_graph_from_keyframes_host():
+    from types import SimpleNamespace
+    from neural_spectral_codec_amd.keyframe.graph_manager import build_graph_from_keyframes
+    rng = np.random.default_rng(0)
+    kfs = [SimpleNamespace(descriptor=rng.random(800).astype(np.float32)) for _ in range(7)]
+    g = build_graph_from_keyframes(kfs, temporal_neighbors=5)
+    assert tuple(g.x.shape) == (7, 800) and g.edge_attr is None
+    assert (g.edge_index.numpy() == ko.chain_graph_loop(7, 5)[0]).all()
+    assert build_graph_from_keyframes([], 5) is None
+
+
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("nb", [50, 800])

@@ -1,10 +1,15 @@
-"""Training step of the GNN on MI355X: TripletLoss + the per-batch step of GNNTrainer.train_epoch.
+"""Training of the GNN on MI355X -- mirror of the reference's src/gnn/trainer.py.
 
-Mirrors reference src/gnn/trainer.py: ``TripletLoss`` (:27-68) and the inner loop of
-``GNNTrainer.train_epoch`` (:186-231: full-graph forward per 1 024-triplet batch, loss / 4,
-backward, Adam step every 4 batches).  Triplet mining (src/gnn/triplet_miner.py) stays on the host
-as in the reference and is not part of this package.
+``TripletLoss`` (:27-68) and ``GNNTrainer`` (:70-495) keep their names, constructor arguments, methods
+(``train_epoch``, ``validate``, ``train``, ``save_checkpoint``, ``load_checkpoint``) and the checkpoint keys; the
+compute inside them runs through the C ABI: full-graph forward + backward per 1 024-triplet batch
+(nsc_gat_forward_train / nsc_gat_backward / nsc_triplet_loss), hard-negative mining on the device
+(gnn/triplet_miner.py), loop-closure recall on the device.  The epoch / early-stopping / checkpoint loop around
+them is host code, as in the reference.
 """
+import logging
+import time
+from pathlib import Path
 from typing import Optional, Sequence
 
 import numpy as np
@@ -66,19 +71,32 @@ class TripletLoss(nn.Module):
 
 
 class GNNTrainer:
-    """The optimisation step of reference GNNTrainer (trainer.py:71-236) without logging, mining,
-    validation and checkpoint plumbing: Adam(lr, weight_decay) over the model parameters, TripletLoss,
-    gradient accumulation over ``accumulation_steps`` batches of ``batch_size`` triplets."""
+    """Reference GNNTrainer (trainer.py:70-495): Adam(lr, weight_decay) over the model parameters, TripletLoss,
+    gradient accumulation over ``accumulation_steps`` batches of ``batch_size`` triplets (1 024 / 4 are literals
+    in the reference, :187-188).  ``use_multi_gpu`` is accepted for signature compatibility: the reference wraps
+    the model in nn.DataParallel (:106-108); here multi-GPU training is one process per GPU -- under an initialised
+    ``torch.distributed`` group every batch's triplets are split over the ranks and the gradients are all-reduced
+    once per optimizer step."""
 
     def __init__(self, model: nn.Module, device: str = 'cuda', learning_rate: float = 5e-4,
-                 weight_decay: float = 1e-5, margin: float = 0.1, batch_size: int = 1024,
-                 accumulation_steps: int = 4):
+                 weight_decay: float = 1e-5, margin: float = 0.1, checkpoint_dir: Optional[str] = None,
+                 log_interval: int = 10, use_multi_gpu: bool = True, patience: int = 10,
+                 batch_size: int = 1024, accumulation_steps: int = 4):
         self.model = model.to(device)
         self.device = device
+        self.patience = patience                                                                      # :112
+        self.epochs_without_improvement = 0
         self.optimizer = optim.Adam(model.parameters(), lr=learning_rate, weight_decay=weight_decay)  # :115-119
         self.criterion = TripletLoss(margin=margin)                                                   # :121
         self.batch_size, self.accumulation_steps = batch_size, accumulation_steps
+        # the reference creates 'checkpoints/' eagerly (:123-124); here the directory appears with the first save
+        self.checkpoint_dir = Path(checkpoint_dir if checkpoint_dir is not None else 'checkpoints')
+        self.log_interval = log_interval
+        self.epoch = 0                                                                                # :129-135
         self.global_step = 0
+        self.best_val_metric = 0.0
+        self.train_losses = []
+        self.val_metrics = []
 
     # -- validation (trainer.py:238-387) ------------------------------------------------------
     def _recall_ranks(self, embeddings: torch.Tensor, poses: np.ndarray, max_k: int,
@@ -138,6 +156,87 @@ class GNNTrainer:
         rec = lambda k: (float(((ranks > 0) & (ranks <= k)).sum().item()) / nq) if nq else 0.0   # noqa: E731
         return {'recall@1': rec(1), 'recall@5': rec(5), 'recall@10': rec(10), 'n_queries': nq}
 
+    def train_epoch(self, graph, triplet_miner, poses: np.ndarray, descriptors: np.ndarray,
+                    sequence_ids: np.ndarray = None, n_triplets_per_anchor: int = 1) -> float:
+        """trainer.py:137-236: mine triplets for the epoch, shuffle them, run the accumulation loop."""
+        t0 = time.perf_counter()
+        triplets = triplet_miner.mine_triplets(descriptors=descriptors, poses=poses,
+                                               n_triplets_per_anchor=n_triplets_per_anchor,
+                                               sequence_ids=sequence_ids)                             # :161-166
+        if len(triplets) == 0:
+            logging.warning("No valid triplets mined!")
+            return 0.0
+        logging.info(f"Mined {len(triplets):,} triplets in {time.perf_counter() - t0:.2f}s")
+        graph = graph.to(self.device)                                                                 # :180
+        triplets = np.array(triplets)
+        np.random.shuffle(triplets)                                                                   # :183-184
+        avg_loss = self.train_batches(graph, triplets)
+        self.train_losses.append(avg_loss)                                                            # :234
+        return avg_loss
+
+    def train(self, train_graph, train_poses: np.ndarray, train_descriptors: np.ndarray,
+              train_sequence_ids: np.ndarray = None, val_graph=None, val_poses: Optional[np.ndarray] = None,
+              n_epochs: int = 50, triplet_miner=None):
+        """trainer.py:389-476: epochs of train_epoch + validate, best / periodic / final checkpoints,
+        early stopping on recall@1."""
+        if triplet_miner is None:
+            from .triplet_miner import create_triplet_miner
+            triplet_miner = create_triplet_miner()
+        for epoch in range(n_epochs):
+            self.epoch = epoch
+            t0 = time.perf_counter()
+            avg_loss = self.train_epoch(train_graph, triplet_miner, train_poses, train_descriptors,
+                                        sequence_ids=train_sequence_ids)
+            if val_graph is not None and val_poses is not None:
+                metrics = self.validate(val_graph, val_poses)
+                self.val_metrics.append(metrics)
+                logging.info(f"Epoch {epoch + 1}/{n_epochs} | Loss: {avg_loss:.4f} | R@1: {metrics['recall@1']:.4f} | "
+                             f"Time: {time.perf_counter() - t0:.1f}s")
+                if metrics['recall@1'] > self.best_val_metric:                                        # :446-455
+                    self.best_val_metric = metrics['recall@1']
+                    self.save_checkpoint('best_model.pth')
+                    self.epochs_without_improvement = 0
+                else:
+                    self.epochs_without_improvement += 1
+                if self.epochs_without_improvement >= self.patience:                                  # :457-461
+                    logging.info(f"Early stopping after {self.patience} epochs without improvement")
+                    break
+            else:
+                logging.info(f"Epoch {epoch + 1}/{n_epochs} | Loss: {avg_loss:.4f} | "
+                             f"Time: {time.perf_counter() - t0:.1f}s")
+            if (epoch + 1) % 10 == 0:                                                                 # :467-468
+                self.save_checkpoint(f'checkpoint_epoch_{epoch + 1}.pth')
+        self.save_checkpoint('final_model.pth')                                                       # :472
+
+    def save_checkpoint(self, filename: str):
+        """trainer.py:478-495: same keys, so the files are interchangeable with the reference's."""
+        self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
+        torch.save({
+            'epoch': self.epoch,
+            'global_step': self.global_step,
+            'model_state_dict': self.model.state_dict(),
+            'optimizer_state_dict': self.optimizer.state_dict(),
+            'best_val_metric': self.best_val_metric,
+            'train_losses': self.train_losses,
+            'val_metrics': self.val_metrics,
+            'epochs_without_improvement': self.epochs_without_improvement,
+        }, self.checkpoint_dir / filename)
+
+    def load_checkpoint(self, filename: str):
+        """trainer.py:497-518."""
+        load_path = self.checkpoint_dir / filename
+        if not load_path.exists():
+            raise FileNotFoundError(f"Checkpoint not found: {load_path}")
+        ck = torch.load(load_path, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ck['model_state_dict'])
+        self.optimizer.load_state_dict(ck['optimizer_state_dict'])
+        self.epoch = ck['epoch']
+        self.global_step = ck['global_step']
+        self.best_val_metric = ck['best_val_metric']
+        self.train_losses = ck.get('train_losses', [])
+        self.val_metrics = ck.get('val_metrics', [])
+        self.epochs_without_improvement = ck.get('epochs_without_improvement', 0)
+
     def train_batches(self, graph, triplets: Sequence) -> float:
         """trainer.py:186-231 for an (n,3) array of (anchor, positive, negative) triplets."""
         self.model.train()
@@ -167,3 +266,11 @@ class GNNTrainer:
         if not losses:
             return 0.0
         return float(torch.stack(losses).mean().item() * self.accumulation_steps)
+
+
+def create_trainer(model: Optional[nn.Module] = None, device: str = 'cuda', **kwargs) -> GNNTrainer:
+    """trainer.py:521-541"""
+    if model is None:
+        from .model import create_spectral_gnn
+        model = create_spectral_gnn()
+    return GNNTrainer(model=model, device=device, **kwargs)

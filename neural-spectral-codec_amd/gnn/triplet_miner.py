@@ -92,3 +92,13 @@ class TripletMiner:
             return []
         allt = torch.cat(out, 0).cpu().numpy()
         return [tuple(int(v) for v in row) for row in allt]
+
+
+def create_triplet_miner(positive_distance_max: float = 5.0, positive_temporal_min: int = 30,
+                         negative_distance_min: float = 10.0, negative_distance_max: float = 50.0,
+                         negative_temporal_min: int = 30, mining_strategy: str = "hard",
+                         device: str = "cuda") -> TripletMiner:
+    """triplet_miner.py:512-541"""
+    return TripletMiner(positive_distance_max=positive_distance_max, positive_temporal_min=positive_temporal_min,
+                        negative_distance_min=negative_distance_min, negative_distance_max=negative_distance_max,
+                        negative_temporal_min=negative_temporal_min, mining_strategy=mining_strategy, device=device)

@@ -1,5 +1,8 @@
 """Mirror of the reference's ``retrieval`` package for stage-1 (Wasserstein) retrieval."""
-from .wasserstein import (WassersteinRetriever, wasserstein_distance_batch_torch,
-                          wasserstein_distance_matrix_torch)
+from .wasserstein import (WassersteinRetriever, wasserstein_distance_1d_numpy, wasserstein_distance_1d_torch,
+                          wasserstein_distance_batch_numpy, wasserstein_distance_batch_torch,
+                          wasserstein_distance_matrix_numpy, wasserstein_distance_matrix_torch)
 
-__all__ = ["WassersteinRetriever", "wasserstein_distance_batch_torch", "wasserstein_distance_matrix_torch"]
+__all__ = ["WassersteinRetriever", "wasserstein_distance_1d_numpy", "wasserstein_distance_1d_torch",
+           "wasserstein_distance_batch_numpy", "wasserstein_distance_batch_torch",
+           "wasserstein_distance_matrix_numpy", "wasserstein_distance_matrix_torch"]

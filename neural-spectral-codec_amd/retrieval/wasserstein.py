@@ -90,6 +90,46 @@ def wasserstein_distance_matrix_torch(hists1: torch.Tensor, hists2: Optional[tor
     return _distances(h2, _cdf(h1, epsilon, False), epsilon)
 
 
+def wasserstein_distance_1d_torch(hist1: torch.Tensor, hist2: torch.Tensor, epsilon: float = 1e-8) -> torch.Tensor:
+    """Two (n_bins,) histograms, both normalised by their plain sum -> scalar tensor   wasserstein.py:55-87"""
+    h1 = _dev_f32(hist1)
+    h2 = _dev_f32(hist2, h1.device)
+    c = _cdf(torch.stack([h1.reshape(-1), h2.reshape(-1)]), epsilon, True)
+    return (c[0] - c[1]).abs().sum()
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise _lib.NscError("the Wasserstein functions run on a HIP device; none is available (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def wasserstein_distance_1d_numpy(hist1: np.ndarray, hist2: np.ndarray, epsilon: float = 1e-8) -> float:
+    """wasserstein.py:20-52 with host arrays in and a Python float out (computed on the device)."""
+    dev = _default_device()
+    return float(wasserstein_distance_1d_torch(torch.from_numpy(np.asarray(hist1, dtype=np.float32)).to(dev),
+                                               torch.from_numpy(np.asarray(hist2, dtype=np.float32)).to(dev),
+                                               epsilon).item())
+
+
+def wasserstein_distance_batch_numpy(query_hist: np.ndarray, database_hists: np.ndarray,
+                                     epsilon: float = 1e-8) -> np.ndarray:
+    """wasserstein.py:90-131: (n_bins,) vs (n_database, n_bins) -> (n_database,) ndarray."""
+    dev = _default_device()
+    return wasserstein_distance_batch_torch(torch.from_numpy(np.asarray(query_hist, dtype=np.float32)).to(dev),
+                                            torch.from_numpy(np.asarray(database_hists, dtype=np.float32)).to(dev),
+                                            epsilon).cpu().numpy()
+
+
+def wasserstein_distance_matrix_numpy(hists1: np.ndarray, hists2: Optional[np.ndarray] = None,
+                                      epsilon: float = 1e-8) -> np.ndarray:
+    """wasserstein.py:175-229: (n1, n_bins) x (n2, n_bins) -> (n1, n2) ndarray."""
+    dev = _default_device()
+    h1 = torch.from_numpy(np.asarray(hists1, dtype=np.float32)).to(dev)
+    h2 = None if hists2 is None else torch.from_numpy(np.asarray(hists2, dtype=np.float32)).to(dev)
+    return wasserstein_distance_matrix_torch(h1, h2, epsilon).cpu().numpy()
+
+
 class WassersteinRetriever:
     """wasserstein.py:276-389 (``use_torch`` is accepted for signature compatibility; the database
     always lives in HBM)."""

@@ -33,6 +33,17 @@ def matrix(h1, h2=None, eps=1e-8):
     return np.abs(c1[:, None, :] - c2[None, :, :]).sum(axis=2, dtype=np.float32)
 
 
+def one_d(h1, h2, eps=1e-8):
+    """wasserstein_distance_1d_numpy / _torch, wasserstein.py:20-87: both histograms divided by their plain sum."""
+    h1, h2 = np.asarray(h1, np.float32), np.asarray(h2, np.float32)
+    s1, s2 = h1.sum(dtype=np.float32), h2.sum(dtype=np.float32)
+    if s1 > eps:
+        h1 = h1 / s1
+    if s2 > eps:
+        h2 = h2 / s2
+    return float(np.abs(np.cumsum(h1, dtype=np.float32) - np.cumsum(h2, dtype=np.float32)).sum(dtype=np.float32))
+
+
 def topk(dist, k):
     """WassersteinRetriever.query, wasserstein.py:360-366: k smallest, ascending (ties: lower index)."""
     order = np.lexsort((np.arange(len(dist)), dist))[:k]

@@ -21,6 +21,10 @@ def test_oracle_matches_reference():
     idx, dist = ro.topk(ro.batch(G["q"][0], G["db"]), 10)
     assert idx.tolist() == G["top_idx"].tolist()
     assert np.allclose(dist, G["top_dist"], rtol=RTOL)
+    for (i, j), d in zip(G["pairs"], G["d_1d"]):                     # the numpy-side functions of the reference
+        assert abs(ro.one_d(G["q"][i], G["db"][j]) - d) <= RTOL * abs(d) + 1e-5
+    assert np.allclose(ro.batch(G["q"][2], G["db"]), G["d_batch_np"], rtol=RTOL, atol=1e-5)
+    assert np.allclose(ro.matrix(G["q"], G["db"][:50]), G["d_mat_np"], rtol=RTOL, atol=1e-5)
 
 
 @pytest.mark.gpu
@@ -35,6 +39,16 @@ def test_gpu_distances_and_topk():
     assert np.allclose(wasserstein_distance_matrix_torch(q, db).cpu().numpy(), G["d_mat"], rtol=RTOL, atol=1e-5)
     small = torch.from_numpy(G["small"]).cuda()                      # 50 bins: other lane layout
     assert np.allclose(wasserstein_distance_matrix_torch(small).cpu().numpy(), G["d_small"], rtol=RTOL, atol=1e-5)
+    # host-array signatures of the reference (wasserstein.py:20-52, :90-131, :175-229), computed on the device
+    from neural_spectral_codec_amd.retrieval import (wasserstein_distance_1d_numpy, wasserstein_distance_1d_torch,
+                                                     wasserstein_distance_batch_numpy, wasserstein_distance_matrix_numpy)
+    for (i, j), want in zip(G["pairs"], G["d_1d"]):
+        got = wasserstein_distance_1d_numpy(G["q"][i], G["db"][j])
+        assert isinstance(got, float) and abs(got - want) <= RTOL * abs(want) + 1e-5
+        assert abs(float(wasserstein_distance_1d_torch(q[i], db[j])) - want) <= RTOL * abs(want) + 1e-5
+    dn = wasserstein_distance_batch_numpy(G["q"][2], G["db"])
+    assert isinstance(dn, np.ndarray) and np.allclose(dn, G["d_batch_np"], rtol=RTOL, atol=1e-5)
+    assert np.allclose(wasserstein_distance_matrix_numpy(G["q"], G["db"][:50]), G["d_mat_np"], rtol=RTOL, atol=1e-5)
     r = WassersteinRetriever(device="cuda")
     r.add_to_database(G["db"][:100])
     r.add_to_database(torch.from_numpy(G["db"][100:]))

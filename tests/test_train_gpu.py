@@ -144,3 +144,39 @@ def test_dropout_masks():
     with torch.no_grad():
         e = m(g)
     assert torch.isfinite(e).all()
+
+
+def test_trainer_epoch_loop_and_checkpoints(tmp_path):
+    """GNNTrainer.train (trainer.py:389-476): mining + accumulation loop + validation + checkpoints, end to end on a
+    two-lap trajectory (revisits exist), then a checkpoint round trip into a fresh trainer."""
+    from neural_spectral_codec_amd.gnn.trainer import create_trainer
+    from neural_spectral_codec_amd.gnn.triplet_miner import create_triplet_miner
+    from neural_spectral_codec_amd.keyframe.graph_manager import build_chain_graph
+    rng = np.random.default_rng(0)
+    n = 300
+    t = np.linspace(0, 4 * np.pi, n)
+    poses = np.tile(np.eye(4), (n, 1, 1))
+    poses[:, 0, 3], poses[:, 1, 3] = 40 * np.cos(t) + rng.normal(0, .3, n), 40 * np.sin(t) + rng.normal(0, .3, n)
+    desc = (rng.random((n, 800)) ** 4).astype(np.float32)
+    desc /= desc.sum(1, keepdims=True)
+    graph = build_chain_graph(torch.from_numpy(desc), 5, "cuda", poses)
+    torch.manual_seed(0)
+    m = create_spectral_gnn(edge_dim=2, dropout=0.0)
+    tr = create_trainer(m, device="cuda", checkpoint_dir=str(tmp_path), batch_size=128, accumulation_steps=2, patience=5)
+    tr.train(graph, poses, desc, train_sequence_ids=np.zeros(n, int), val_graph=graph, val_poses=poses, n_epochs=2,
+             triplet_miner=create_triplet_miner())
+    assert len(tr.train_losses) == 2 and all(np.isfinite(tr.train_losses)) and tr.global_step > 0
+    assert len(tr.val_metrics) == 2 and set(tr.val_metrics[0]) >= {"recall@1", "recall@5", "recall@10"}
+    assert (tmp_path / "final_model.pth").exists()
+    ck = torch.load(tmp_path / "final_model.pth", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "global_step", "model_state_dict", "optimizer_state_dict", "best_val_metric",
+                       "train_losses", "val_metrics", "epochs_without_improvement"}          # trainer.py:480-489
+    m2 = create_spectral_gnn(edge_dim=2, dropout=0.0)
+    tr2 = create_trainer(m2, device="cuda", checkpoint_dir=str(tmp_path))
+    tr2.load_checkpoint("final_model.pth")
+    assert tr2.global_step == tr.global_step and tr2.epoch == tr.epoch
+    m.eval(), m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m(graph), m2(graph))
+    with pytest.raises(FileNotFoundError):
+        tr2.load_checkpoint("missing.pth")

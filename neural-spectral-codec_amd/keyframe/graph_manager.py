@@ -1,4 +1,4 @@
-"""Graph container + offline temporal-graph builder feeding the GNN.
+"""Graph container, offline temporal-graph builder and the online sliding-window manager feeding the GNN.
 
 Mirrors reference src/keyframe/graph_manager.py:471-606 (``build_graph_from_keyframes_batch``):
 chain graph over the flat keyframe list, offsets +-1..+-(M//2), edge_attr = [log1p(d)/5, theta/pi].
@@ -6,7 +6,7 @@ The reference's O(N*M) Python loop is vectorised here (same arithmetic, float64 
 same place).  ``Data`` stands in for ``torch_geometric.data.Data`` (reference :19,599) when PyG is
 not installed; a real PyG ``Data`` is accepted everywhere as well.
 """
-from typing import List, Optional, Tuple
+from typing import List, Optional, Set, Tuple
 
 import numpy as np
 import torch
@@ -140,6 +140,178 @@ def build_graph_from_keyframes_batch(keyframes, temporal_neighbors: int = 5, dev
         return None
     feats = torch.stack([torch.from_numpy(np.asarray(kf.descriptor)).float() for kf in keyframes], 0)
     return build_chain_graph(feats, temporal_neighbors, device, poses, loop_closures)
+
+
+class TemporalGraphManager:
+    """Online sliding-window graph of the inference loop -- same methods and behaviour as the reference's
+    TemporalGraphManager (graph_manager.py:24-441, driven by pipeline.py:250-256), different bookkeeping:
+
+    * descriptors live in a preallocated device buffer; ``add_keyframe`` copies one 800-float row instead of
+      re-stacking every active descriptor (:114-118), the window slides by moving the start of the view;
+    * the temporal edges of an n-node window depend on n only and are cached per n (built by
+      nsc_build_chain_graph on a HIP device);
+    * as in the reference, every ``add_keyframe`` rebuilds the graph from the temporal edges alone, so an edge
+      added by ``add_loop_closure_edge`` lives until the next keyframe arrives (:100, :104-128), and the online
+      graph carries no ``edge_attr`` (:124-128)."""
+
+    def __init__(self, temporal_neighbors: int = 5, max_active_nodes: int = 1000, feature_dim: int = 800,
+                 device: str = 'cpu'):
+        self.temporal_neighbors = temporal_neighbors
+        self.max_active_nodes = max_active_nodes
+        self.feature_dim = feature_dim
+        self.device = device
+        self._edge_cache = {}
+        self.reset()
+
+    def reset(self):
+        self.graph = None
+        self.keyframes = []
+        self.frozen_keyframes = []
+        self.frozen_embeddings = None
+        self.keyframe_id_to_node_idx = {}
+        self._buf = None
+        self._start = 0
+
+    # -- internals ----------------------------------------------------------------------------
+    def _edges(self, n: int) -> torch.Tensor:
+        e = self._edge_cache.get(n)
+        if e is None:
+            if torch.device(self.device).type == "cuda":
+                e, _ = chain_graph_device(n, self.temporal_neighbors, self.device)
+            else:
+                ce = chain_edges(n, self.temporal_neighbors)
+                e = (torch.from_numpy(np.ascontiguousarray(ce.T)) if len(ce)
+                     else torch.zeros((2, 0), dtype=torch.long)).to(self.device)
+            if len(self._edge_cache) > 2 * self.max_active_nodes + 8:
+                self._edge_cache.clear()
+            self._edge_cache[n] = e
+        return e
+
+    def _append_row(self, descriptor: np.ndarray):
+        row = torch.from_numpy(np.ascontiguousarray(descriptor, dtype=np.float32))
+        d = int(row.numel())
+        n = len(self.keyframes)                       # the new keyframe is already in the list
+        if self._buf is None:
+            cap = 2 * max(self.max_active_nodes, 1) + 2
+            self._buf = torch.empty((cap, d), dtype=torch.float32, device=self.device)
+            self._start = 0
+        if self._start + n > self._buf.shape[0]:      # slide the window back to the front of the buffer
+            self._buf[:n - 1] = self._buf[self._start:self._start + n - 1].clone()
+            self._start = 0
+        self._buf[self._start + n - 1] = row.to(self.device)
+
+    def _rebuild_graph(self):
+        """:104-128 -- temporal edges only, x = the active rows (a view of the buffer)."""
+        n = len(self.keyframes)
+        if n == 0:
+            self.graph = None
+            return
+        self.graph = Data(x=self._buf[self._start:self._start + n], edge_index=self._edges(n), num_nodes=n)
+
+    def _freeze_oldest_node(self):
+        """:166-202"""
+        if not self.keyframes:
+            return
+        oldest = self.keyframes.pop(0)
+        self.frozen_keyframes.append(oldest)
+        del self.keyframe_id_to_node_idx[oldest.keyframe_id]
+        for k in self.keyframe_id_to_node_idx:
+            self.keyframe_id_to_node_idx[k] -= 1
+        if getattr(oldest, "embedding", None) is not None:
+            emb = torch.from_numpy(np.asarray(oldest.embedding)).float().to(self.device).unsqueeze(0)
+            self.frozen_embeddings = emb if self.frozen_embeddings is None else torch.cat([self.frozen_embeddings, emb], 0)
+        self._start += 1
+        self._rebuild_graph()
+
+    # -- reference API ------------------------------------------------------------------------
+    def add_keyframe(self, keyframe) -> int:
+        """:75-102 -> node index in the active graph"""
+        if keyframe.descriptor is None:
+            raise ValueError("Keyframe must have descriptor computed before adding to graph")
+        self.keyframes.append(keyframe)
+        node_idx = len(self.keyframes) - 1
+        self.keyframe_id_to_node_idx[keyframe.keyframe_id] = node_idx
+        self._append_row(keyframe.descriptor)
+        self._rebuild_graph()
+        if len(self.keyframes) > self.max_active_nodes:
+            self._freeze_oldest_node()
+        return node_idx
+
+    def get_graph(self):
+        return self.graph
+
+    def add_loop_closure_edge(self, query_keyframe_id: int, match_keyframe_id: int, pose_query: np.ndarray = None,
+                              pose_match: np.ndarray = None) -> bool:
+        """:208-272 -- bidirectional edge between two ACTIVE keyframes (edge features only if the graph has any)."""
+        qi = self.keyframe_id_to_node_idx.get(query_keyframe_id)
+        mi = self.keyframe_id_to_node_idx.get(match_keyframe_id)
+        if qi is None or mi is None or self.graph is None:
+            return False
+        new = torch.tensor([[qi, mi], [mi, qi]], dtype=torch.long, device=self.device)
+        self.graph.edge_index = torch.cat([self.graph.edge_index, new], 1)
+        if pose_query is not None and pose_match is not None and getattr(self.graph, "edge_attr", None) is not None:
+            f = edge_features(np.stack([pose_query, pose_match]), np.array([[0, 1], [0, 1]]))
+            self.graph.edge_attr = torch.cat([self.graph.edge_attr, torch.from_numpy(f).to(self.device)], 0)
+        return True
+
+    def get_node_index(self, keyframe_id: int) -> Optional[int]:
+        return self.keyframe_id_to_node_idx.get(keyframe_id, None)
+
+    def get_k_hop_neighbors(self, node_idx: int, k: int) -> Set[int]:
+        """:286-320 -- breadth-first over outgoing edges"""
+        if self.graph is None or k <= 0:
+            return {node_idx}
+        ei = self.graph.edge_index.cpu().numpy()
+        seen, layer = {node_idx}, {node_idx}
+        for _ in range(k):
+            nxt = set(ei[1, np.isin(ei[0], list(layer))].tolist()) if layer else set()
+            seen |= nxt
+            layer = nxt
+            if not layer:
+                break
+        return seen
+
+    def get_local_subgraph(self, node_idx: int, k_hops: int = 3):
+        """:322-375 -> (subgraph, {original index: subgraph index})"""
+        if self.graph is None:
+            raise ValueError("Graph is empty")
+        nodes = sorted(self.get_k_hop_neighbors(node_idx, k_hops))
+        mapping = {old: new for new, old in enumerate(nodes)}
+        ei = self.graph.edge_index.cpu().numpy()
+        keep = np.isin(ei[0], nodes) & np.isin(ei[1], nodes)
+        lut = np.full(int(self.graph.num_nodes), -1, dtype=np.int64)
+        lut[nodes] = np.arange(len(nodes))
+        sub = lut[ei[:, keep]]
+        sub_ei = (torch.from_numpy(np.ascontiguousarray(sub)) if sub.size
+                  else torch.zeros((2, 0), dtype=torch.long)).to(self.device)
+        idx = torch.as_tensor(nodes, dtype=torch.long, device=self.graph.x.device)
+        return Data(x=self.graph.x[idx], edge_index=sub_ei, num_nodes=len(nodes)), mapping
+
+    def update_embeddings(self, embeddings: torch.Tensor):
+        """:377-393"""
+        if len(embeddings) != len(self.keyframes):
+            raise ValueError(f"Embedding count ({len(embeddings)}) != keyframe count ({len(self.keyframes)})")
+        emb = embeddings.detach().cpu().numpy()
+        for i, kf in enumerate(self.keyframes):
+            kf.embedding = emb[i]
+
+    def get_all_keyframes(self) -> list:
+        return self.frozen_keyframes + self.keyframes
+
+    def get_all_descriptors(self) -> np.ndarray:
+        return np.array([kf.descriptor for kf in self.get_all_keyframes()])
+
+    def get_all_embeddings(self) -> Optional[np.ndarray]:
+        kfs = self.get_all_keyframes()
+        if getattr(kfs[0], "embedding", None) is None:
+            return None
+        return np.array([kf.embedding for kf in kfs])
+
+    def get_statistics(self) -> dict:
+        ne = int(self.graph.edge_index.shape[1]) if self.graph is not None else 0
+        return {'num_active_nodes': len(self.keyframes), 'num_frozen_nodes': len(self.frozen_keyframes),
+                'total_nodes': len(self.keyframes) + len(self.frozen_keyframes), 'num_edges': ne,
+                'avg_degree': ne / len(self.keyframes) if self.graph is not None and self.keyframes else 0.0}
 
 
 def build_graph_from_keyframes(keyframes, temporal_neighbors: int = 5, device: str = 'cpu'):

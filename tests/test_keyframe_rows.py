@@ -325,3 +325,65 @@ def test_empty_inputs():
     assert tuple(g.edge_index.shape) == (2, 0)
     iou = pu.compute_overlap_batch([], [], np.zeros((0, 4, 4)))
     assert tuple(iou.shape) == (0,)
+
+
+def _literal_window(descs, ids, max_active, m):
+    """What graph_manager.py:75-202 leaves after feeding the keyframes one by one: (active ids, x, edge_index)."""
+    act = []
+    for i in ids:
+        act.append(i)
+        if len(act) > max_active:
+            act.pop(0)
+    x = np.stack([descs[i] for i in act])
+    return act, x, ko.chain_graph_loop(len(act), m)[0]
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_temporal_graph_manager(device):
+    from types import SimpleNamespace
+    from neural_spectral_codec_amd.keyframe.graph_manager import TemporalGraphManager
+    rng = np.random.default_rng(1)
+    descs = {i: rng.random(800).astype(np.float32) for i in range(40)}
+    mgr = TemporalGraphManager(temporal_neighbors=5, max_active_nodes=6, device=device)
+    assert mgr.get_graph() is None and mgr.get_statistics()["num_edges"] == 0
+    kfs = {}
+    for step, i in enumerate(range(40)):
+        kfs[i] = SimpleNamespace(keyframe_id=1000 + i, descriptor=descs[i], embedding=None)
+        idx = mgr.add_keyframe(kfs[i])
+        act, x, ei = _literal_window(descs, list(range(step + 1)), 6, 5)
+        g = mgr.get_graph()
+        assert idx == min(step, 6)                                     # index at insertion, before the window slides
+        assert g.num_nodes == len(act) and (g.x.cpu().numpy() == x).all()
+        assert (g.edge_index.cpu().numpy() == ei).all() and getattr(g, "edge_attr", None) is None
+        assert [mgr.get_node_index(1000 + a) for a in act] == list(range(len(act)))
+        if step == 20:                                                 # embeddings of the active window get cached on freeze
+            mgr.update_embeddings(torch.arange(len(act) * 4, dtype=torch.float32).reshape(len(act), 4))
+    st = mgr.get_statistics()
+    assert st == {"num_active_nodes": 6, "num_frozen_nodes": 34, "total_nodes": 40, "num_edges": 18, "avg_degree": 3.0}
+    assert mgr.frozen_embeddings is not None and tuple(mgr.frozen_embeddings.shape) == (6, 4)
+    assert mgr.get_all_descriptors().shape == (40, 800) and mgr.get_node_index(1000) is None
+    # loop closure between active keyframes: bidirectional, gone again after the next rebuild (reference behaviour)
+    assert mgr.add_loop_closure_edge(1034, 1039) and not mgr.add_loop_closure_edge(1000, 1039)
+    g = mgr.get_graph()
+    assert g.edge_index.shape[1] == 20 and g.edge_index[:, -2:].cpu().tolist() == [[0, 5], [5, 0]]
+    assert mgr.get_k_hop_neighbors(0, 1) == {0, 1, 2, 5} and mgr.get_k_hop_neighbors(3, 0) == {3}
+    sub, mapping = mgr.get_local_subgraph(0, 1)
+    assert mapping == {0: 0, 1: 1, 2: 2, 5: 3} and sub.num_nodes == 4
+    assert (sub.x.cpu().numpy() == g.x.cpu().numpy()[[0, 1, 2, 5]]).all()
+    assert sorted(map(tuple, sub.edge_index.t().cpu().tolist())) == sorted(
+        [(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1), (0, 3), (3, 0)])
+    mgr.add_keyframe(SimpleNamespace(keyframe_id=5000, descriptor=descs[0], embedding=None))
+    assert mgr.get_graph().edge_index.shape[1] == 18
+    with pytest.raises(ValueError):
+        mgr.add_keyframe(SimpleNamespace(keyframe_id=1, descriptor=None, embedding=None))
+    with pytest.raises(ValueError):
+        mgr.update_embeddings(torch.zeros((3, 4)))
+    if device == "cuda":                                               # the online loop of pipeline.py:250-256
+        from neural_spectral_codec_amd.gnn.model import create_spectral_gnn
+        gnn = create_spectral_gnn(edge_dim=None).cuda().eval()
+        with torch.no_grad():
+            emb = gnn(mgr.get_graph())
+        mgr.update_embeddings(emb)
+        assert mgr.get_all_keyframes()[-1].embedding.shape == (800,)
+    mgr.reset()
+    assert mgr.get_graph() is None and mgr.get_statistics()["total_nodes"] == 0

@@ -67,7 +67,13 @@ __host__ __device__ inline LdsPlan lds_plan(int E, int R, int B, int nw)
     p.img = o;  o += E * ROW_BYTES;
     p.pool = o; o += (E != R) ? R * ROW_BYTES : 0;
     p.tw = o;   o += TW_N * 16;
-    p.fft = o;  o += nw * NH * 16;
+    // With row pooling the FFT reads the pooled rows, the E-row image is dead by then: the per-wave FFT scratch
+    // goes into it when it fits (a 64-row image + its own scratch would not fit the 160 KB of a CU otherwise).
+    if (E != R && E * ROW_BYTES >= nw * NH * 16) {
+        p.fft = p.img;
+    } else {
+        p.fft = o;  o += nw * NH * 16;
+    }
     p.seg = o;  o += ((2 * B * 4) + 15) & ~15;
     p.misc = o; o += MAXR * 8 + MAXE * 4 + MAXE * 4;   // rowsum f64[16], rowflag int[64], rowsrc int[64]
     p.total = o;
@@ -816,13 +822,21 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
         hipLaunchKernelGGL(k, dim3(n_clouds), dim3(NW_ * 64), lpv.total, stream, pts, off, stride, d, \
                            lut, out_desc, out_raw, out_interp);                                       \
     }
-        switch (variant) {
-        case 1: NSC_LAUNCH_FUSED(4, 4, 4) break;
-        case 2: NSC_LAUNCH_FUSED(8, 8, 4) break;
+        // 16 waves per CU in every shape: the LDS image decides how many workgroups share a CU, the workgroup
+        // brings the waves (E <= 16: 4 x 4 waves, <= 32 rows: 2 x 8, up to 64 rows: 1 x 16)
+        if (d.E > 32) {
+            if (variant == 1) NSC_LAUNCH_FUSED(16, 8, 1) else NSC_LAUNCH_FUSED(16, 4, 1)
+        } else if (d.E > 16) {
+            if (variant == 1) NSC_LAUNCH_FUSED(8, 8, 2) else NSC_LAUNCH_FUSED(8, 4, 2)
+        } else switch (variant) {
+        case 1: NSC_LAUNCH_FUSED(4, 8, 4) break;
         case 3: NSC_LAUNCH_FUSED(8, 4, 4) break;
-        // default: 4 waves x 8 float4 loads in flight per lane, 39.4 KB LDS -> 4 workgroups per CU:
-        // a 1 024-cloud batch is exactly one resident round (interleaved A/B, profiles/r01_*).
-        default: NSC_LAUNCH_FUSED(4, 8, 4) break;
+        case 4: NSC_LAUNCH_FUSED(8, 8, 2) break;
+        case 5: NSC_LAUNCH_FUSED(16, 8, 1) break;
+        // default: 4 waves x 4 float4 loads in flight per lane (92 VGPRs), 39.4 KB LDS -> 4 workgroups per CU:
+        // a 1 024-cloud batch is exactly one resident round.  Interleaved A/B on three boxes: 1-1.5 % faster than 8
+        // loads per lane (108 VGPRs), and it leaves 128 VGPRs per SIMD lane to co-resident kernels.
+        default: NSC_LAUNCH_FUSED(4, 4, 4) break;
         }
     } else {
         const size_t need = (size_t)n_clouds * d.E * A * sizeof(unsigned);

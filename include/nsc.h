@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NSC_ABI_VERSION 1
+#define NSC_ABI_VERSION 2
 
 typedef enum NscStatus {
     NSC_OK            = 0,
@@ -221,6 +221,7 @@ typedef struct NscGatGradLayer {   /* device buffers shaped like the NscGatLayer
 typedef struct NscGatGrads {
     float *in_w, *in_b, *in_bn_w, *in_bn_b, *out_w, *out_b;
     float *x;                      /* nullable: gradient w.r.t. the input features (n_nodes, in_dim) */
+    float *res_w, *res_b;          /* residual_proj (model.py:91-94): required iff residual && in_dim != out_dim */
     NscGatGradLayer layers[NSC_GAT_MAX_LAYERS];
 } NscGatGrads;
 
@@ -229,7 +230,7 @@ int    nsc_graph_transpose(const NscGraph *g, int32_t *t_ptr, int32_t *t_entry, 
                            size_t ws_bytes, void *stream);
 
 /* The workspace holds the activations the forward saves for the backward: pass the SAME buffer (and
- * cfg) to nsc_gat_backward.  Requires in_dim == out_dim when residual is set (the reference's shape). */
+ * cfg) to nsc_gat_backward.  residual && in_dim != out_dim trains residual_proj (m->res_w / res_b). */
 size_t nsc_gat_train_workspace_bytes(const NscGatModel *m, const NscGraph *g);
 int    nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                              const NscGatTrainCfg *cfg, float *out, void *ws, size_t ws_bytes, void *stream);
@@ -238,7 +239,9 @@ int    nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x,
                         size_t ws_bytes, void *stream);
 
 /* TripletLoss forward (+ backward when grad_emb != NULL): loss = scale * mean_t relu(|a-p|^2 - |a-n|^2 + margin);
- * grad_emb (n_nodes, dim) is zeroed and receives d loss / d emb. */
+ * grad_emb (n_nodes, dim) is zeroed and receives d loss / d emb.  Indices follow embeddings[idx] (trainer.py:207-209):
+ * values in [-n_nodes, 0) wrap; a triplet with an index outside [-n_nodes, n_nodes) reads and writes nothing and turns
+ * the loss into NaN (the reference raises IndexError there). */
 size_t nsc_triplet_workspace_bytes(int32_t n_triplets);
 int    nsc_triplet_loss(const float *emb, const int64_t *anchors, const int64_t *positives,
                         const int64_t *negatives, int32_t n_triplets, int32_t n_nodes, int32_t dim,

@@ -30,6 +30,7 @@ class GatLayer(C.Structure):
         "bn_w", "bn_b", "bn_mean", "bn_var")]
 
 
+ABI_VERSION = 2            # NSC_ABI_VERSION of include/nsc.h
 GAT_MAX_LAYERS = 8
 GAT_MAX_EDGE_DIM = 8
 
@@ -77,7 +78,8 @@ class GatGradLayer(C.Structure):
 
 class GatGrads(C.Structure):
     """struct NscGatGrads"""
-    _fields_ = [(n, C.c_void_p) for n in ("in_w", "in_b", "in_bn_w", "in_bn_b", "out_w", "out_b", "x")] + [
+    _fields_ = [(n, C.c_void_p) for n in ("in_w", "in_b", "in_bn_w", "in_bn_b", "out_w", "out_b", "x",
+                                          "res_w", "res_b")] + [
         ("layers", GatGradLayer * GAT_MAX_LAYERS)]
 
 
@@ -151,7 +153,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.nsc_abi_version() != 1:
+        if L.nsc_abi_version() != ABI_VERSION:
             raise NscError("libnsc_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -602,12 +602,20 @@ __global__ __launch_bounds__(256) void tcsr_sort_kernel(const int *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void triplet_kernel(const float *__restrict__ emb, const long long *__restrict__ ia,
                                                       const long long *__restrict__ ip, const long long *__restrict__ in_,
-                                                      int T, int D, float margin, float scale,
+                                                      int T, int N, int D, float margin, float scale,
                                                       float *__restrict__ per_triplet, float *__restrict__ grad)
 {
     const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    const float *a = emb + ia[t] * D, *p = emb + ip[t] * D, *n = emb + in_[t] * D;
+    // embeddings[idx] semantics (trainer.py:207-209): negative indices wrap once; anything still outside [0, N)
+    // would raise IndexError in the reference -- here the triplet touches no memory and poisons the loss with NaN
+    long long a_i = ia[t], p_i = ip[t], n_i = in_[t];
+    a_i += (a_i < 0) ? N : 0; p_i += (p_i < 0) ? N : 0; n_i += (n_i < 0) ? N : 0;
+    if (a_i < 0 || a_i >= N || p_i < 0 || p_i >= N || n_i < 0 || n_i >= N) {
+        if (lane == 0) per_triplet[t] = NAN;
+        return;
+    }
+    const float *a = emb + a_i * D, *p = emb + p_i * D, *n = emb + n_i * D;
     float dp = 0.f, dn = 0.f;
     for (int c = lane; c < D; c += 64) {
         const float x = a[c] - p[c], y = a[c] - n[c];
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(256) void triplet_kernel(const float *__restrict__ 
     if (lane == 0) per_triplet[t] = l > 0.0f ? l : 0.0f;
     if (grad && l > 0.0f) {
         const float g = 2.0f * scale / (float)T;              // d(mean relu)/d(dist) * 2(a - .)
-        float *ga = grad + ia[t] * D, *gp = grad + ip[t] * D, *gn = grad + in_[t] * D;
+        float *ga = grad + a_i * D, *gp = grad + p_i * D, *gn = grad + n_i * D;
         for (int c = lane; c < D; c += 64) {
             const float av = a[c], pv = p[c], nv = n[c];
             atomicAdd(&ga[c], g * (nv - pv));
@@ -683,7 +691,8 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     w.s1 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
     w.s2 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
     w.dvvec = o; o += 256;
-    const size_t big = (size_t)std::max(m->in_dim, m->out_dim) * H;
+    size_t big = (size_t)std::max(m->in_dim, m->out_dim) * H;
+    if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
     w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);
     w.colpart = o; o += align256((size_t)COLRED_MAXR * std::max(std::max(H, m->out_dim), m->in_dim) * 2 * 8);
     w.total = o;
@@ -730,7 +739,7 @@ int check_train(const NscGatModel *m, const NscGraph *g)
     if (m->hidden < 16 || m->hidden > 1024 || (m->hidden & 15)) return NSC_EUNSUPPORTED;
     if (m->in_dim < 16 || (m->in_dim & 15) || m->out_dim < 4 || (m->out_dim & 3)) return NSC_EUNSUPPORTED;
     if (m->edge_dim < 0 || m->edge_dim > NSC_GAT_MAX_EDGE_DIM) return NSC_EUNSUPPORTED;
-    if (m->residual && m->in_dim != m->out_dim) return NSC_EUNSUPPORTED;   // residual_proj: inference only so far
+    if (m->residual && m->in_dim != m->out_dim && (!m->res_w || !m->res_b)) return NSC_EINVAL;   // model.py:91-94
     if (!g->row_ptr || !g->src || !g->eid) return NSC_EINVAL;
     return NSC_OK;
 }
@@ -820,9 +829,12 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
     }
     // output_proj + input residual                                             model.py:144-151
     gemm<false, false>(st, F(w.h + w.nh * L), H, m->out_w, H, N, m->out_dim, H, out, m->out_dim, m->out_b, 0, 1, nullptr);
-    if (m->residual) {
+    if (m->residual && m->in_dim == m->out_dim) {
         const long long tot = (long long)N * m->out_dim;
         hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(tot)), dim3(256), 0, st, out, x, tot);
+    } else if (m->residual) {                                                  // out += residual_proj(x)  model.py:147-149
+        gemm<false, false>(st, x, m->in_dim, m->res_w, m->in_dim, N, m->out_dim, m->in_dim, out, m->out_dim, m->res_b, 1, 1,
+                           nullptr);
     }
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
@@ -852,8 +864,22 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, 0, splits, slabs);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
     gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, nullptr);   // dh_L = dOut W_out
-    if (gr->x) {   // gradient wrt the input features through the residual connection only
-        if (hipMemcpyAsync(gr->x, grad_out, (size_t)N * Din * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+    const bool res_id = m->residual && Din == Dout, res_proj = m->residual && Din != Dout;
+    if (res_proj) {                // residual_proj: dW_res = dOut^T x, db_res = colsum dOut      model.py:147-149
+        if (!gr->res_w || !gr->res_b) return NSC_EINVAL;
+        colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr);
+        gemm<true, true>(st, grad_out, Dout, x, Din, Dout, Din, N, gr->res_w, Din, nullptr, 0, splits, slabs);
+    }
+    if (gr->x) {
+        // gradient wrt the input features through the residual connection: dOut itself (identity residual),
+        // dOut W_res (residual_proj) or nothing (residual=False); dZ0 W_in is accumulated at the end
+        if (res_id) {
+            if (hipMemcpyAsync(gr->x, grad_out, (size_t)N * Din * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+        } else if (res_proj) {
+            gemm<false, true>(st, grad_out, Dout, m->res_w, Din, N, Din, Dout, gr->x, Din, nullptr, 0, 1, nullptr);
+        } else {
+            if (hipMemsetAsync(gr->x, 0, (size_t)N * Din * 4, st) != hipSuccess) return NSC_ELAUNCH;
+        }
     }
 
     for (int l = L - 1; l >= 0; --l) {
@@ -937,7 +963,7 @@ int nsc_triplet_loss(const float *emb, const int64_t *anchors, const int64_t *po
                      int32_t T, int32_t N, int32_t D, float margin, float scale, float *loss, float *grad_emb,
                      void *ws, size_t ws_bytes, void *stream_)
 {
-    if (T < 0 || N < 0 || D < 1) return NSC_EINVAL;
+    if (T < 0 || N < 0 || D < 1 || (T > 0 && N == 0)) return NSC_EINVAL;
     if (!loss) return NSC_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (grad_emb && hipMemsetAsync(grad_emb, 0, (size_t)N * D * 4, st) != hipSuccess) return NSC_ELAUNCH;
@@ -946,7 +972,7 @@ int nsc_triplet_loss(const float *emb, const int64_t *anchors, const int64_t *po
     if (!ws || ws_bytes < nsc_triplet_workspace_bytes(T)) return NSC_EWORKSPACE;
     float *per = static_cast<float *>(ws);
     hipLaunchKernelGGL(triplet_kernel, dim3((T + 3) / 4), dim3(256), 0, st, emb, reinterpret_cast<const long long *>(anchors),
-                       reinterpret_cast<const long long *>(positives), reinterpret_cast<const long long *>(negatives), T, D,
+                       reinterpret_cast<const long long *>(positives), reinterpret_cast<const long long *>(negatives), T, N, D,
                        margin, scale, per, grad_emb);
     hipLaunchKernelGGL(triplet_reduce_kernel, dim3(1), dim3(256), 0, st, per, T, scale, loss);
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;

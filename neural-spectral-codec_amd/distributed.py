@@ -144,28 +144,41 @@ class ShardedDescriptorPath:
 
     def _pipe_setup(self, device):
         inner = getattr(self.gnn, "gnn", self.gnn)
-        inner.coresident = True
-        sE, sG = torch.cuda.Stream(device), torch.cuda.Stream(device)
-        cur = torch.cuda.current_stream(device)
-        sE.wait_stream(cur)
-        sG.wait_stream(cur)
+        if hasattr(inner, "coresident"):
+            inner.coresident = True
         n_local, d = self.hi - self.lo, int(getattr(self.encoder, "output_dim", 800))
         nb = self._PIPE_BUFFERS
+        if device.type == "cuda":
+            sE, sG = torch.cuda.Stream(device), torch.cuda.Stream(device)
+            cur = torch.cuda.current_stream(device)
+            sE.wait_stream(cur)
+            sG.wait_stream(cur)
+            self._ev_enc = [torch.cuda.Event() for _ in range(nb)]
+            self._ev_gnn = [torch.cuda.Event() for _ in range(nb)]
+        else:
+            # host tensors (the gloo tests of the buffer rotation and the exchange): no streams, every launch is
+            # synchronous, so the same issue order runs as a plain sequence
+            sE = sG = None
+            self._ev_enc = self._ev_gnn = [None] * nb
         self._streams = (sE, sG)
         self._desc = [torch.empty((n_local, d), dtype=torch.float32, device=device) for _ in range(nb)]
-        self._ev_enc = [torch.cuda.Event() for _ in range(nb)]
-        self._ev_gnn = [torch.cuda.Event() for _ in range(nb)]
 
     def _step_pipelined(self, clouds, encoder_events, inputs_ready):
-        device = self.encoder.alpha.device
+        device = torch.device(self.encoder.alpha.device)
         if self._streams is None:
             self._pipe_setup(device)
         sE, sG = self._streams
         nb = self._PIPE_BUFFERS
         i = self._k % nb
+        if sE is None:
+            local = self.encoder.encode_points_batch(clouds, out=self._desc[i])
+            res = self._exchange_and_enhance(local)
+            self._k += 1
+            return res
+        caller = torch.cuda.current_stream(device)
         if not inputs_ready:
             # the clouds may still be being written on the caller's stream: order the encoder behind it
-            sE.wait_stream(torch.cuda.current_stream(device))
+            sE.wait_stream(caller)
         with torch.cuda.stream(sE):
             # batch k-nb must have been read out of this buffer.  With nb buffers in rotation that GNN pass
             # has normally finished long ago: ask the host first, so that the encoder stream carries no
@@ -181,13 +194,19 @@ class ShardedDescriptorPath:
             sG.wait_event(done)
             res = self._exchange_and_enhance(local)
             self._ev_gnn[i].record(sG)
+        # emb (and a gathered matrix that is not one of the rotating slots) came out of the caching allocator on
+        # stream G and are read by the caller on ITS stream after synchronize(): tell the allocator, or the block
+        # could be handed to a later step on stream G while those reads are still in flight
+        for t in res:
+            if t.is_cuda:
+                t.record_stream(caller)
         self.last_event = self._ev_gnn[i]
         self._k += 1
         return res
 
     def synchronize(self):
         """Make the caller's current stream wait for every step issued so far (pipeline mode)."""
-        if self._streams is not None:
+        if self._streams is not None and self._streams[0] is not None:
             cur = torch.cuda.current_stream(self._streams[0].device)
             cur.wait_stream(self._streams[0])
             cur.wait_stream(self._streams[1])
@@ -220,7 +239,7 @@ class ShardedDescriptorPath:
             edges_all = torch.empty((self.world * 2 * h, d), dtype=local.dtype, device=local.device)
             dist.all_gather_into_tensor(edges_all, mine, group=self.group)
             # 2. the full matrix, asynchronously
-            slot = (self._k % self._PIPE_BUFFERS) if self.pipeline else 0
+            slot = 0                                 # (overlap is off in pipeline mode, see __init__)
             if slot not in self._desc_all:
                 self._desc_all[slot] = torch.empty((self.n_total, d), dtype=local.dtype, device=local.device)
             gathered = self._desc_all[slot]
@@ -234,6 +253,16 @@ class ShardedDescriptorPath:
                 parts.append(edges_all[(self.rank + 1) * 2 * h:(self.rank + 1) * 2 * h + h])
             self._graph.x = torch.cat(parts, 0) if len(parts) > 1 else local
             desc_all = gathered
+        elif self.pipeline and self.world > 1 and self.n_total % self.world == 0:
+            # pipeline mode: ONE all-gather straight into this step's slot of the rotating gathered-matrix buffers
+            # (valid for _PIPE_BUFFERS - 1 further steps, like the descriptor buffers; no allocation per step)
+            slot = self._k % self._PIPE_BUFFERS
+            if slot not in self._desc_all:
+                self._desc_all[slot] = torch.empty((self.n_total, int(local.shape[1])), dtype=local.dtype,
+                                                   device=local.device)
+            desc_all = self._desc_all[slot]
+            dist.all_gather_into_tensor(desc_all, local.contiguous(), group=self.group)
+            self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]
         else:
             desc_all = all_gather_descriptors(local, self.n_total, self.group)    # fresh tensor per step
             self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]

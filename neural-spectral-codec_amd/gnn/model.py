@@ -134,6 +134,8 @@ class _GatTrainFunction(torch.autograd.Function):
         gs.in_w, gs.in_b = next(it).data_ptr(), next(it).data_ptr()
         gs.in_bn_w, gs.in_bn_b = next(it).data_ptr(), next(it).data_ptr()
         gs.out_w, gs.out_b = next(it).data_ptr(), next(it).data_ptr()
+        if gnn.residual_proj is not None:
+            gs.res_w, gs.res_b = next(it).data_ptr(), next(it).data_ptr()
         for l, conv in enumerate(gnn.convs):
             gl = gs.layers[l]
             gl.lin_w, gl.att_src, gl.att_dst = next(it).data_ptr(), next(it).data_ptr(), next(it).data_ptr()
@@ -261,6 +263,8 @@ class SpectralGNN(nn.Module):
         """Parameters in the order NscGatGrads lists them."""
         ps = [self.input_proj.weight, self.input_proj.bias, self.input_norm.weight, self.input_norm.bias,
               self.output_proj.weight, self.output_proj.bias]
+        if self.residual_proj is not None:
+            ps += [self.residual_proj.weight, self.residual_proj.bias]
         for conv, bn in zip(self.convs, self.batch_norms):
             ps += [conv.lin_src.weight, conv.att_src, conv.att_dst]
             if conv.lin_edge is not None:
@@ -273,8 +277,6 @@ class SpectralGNN(nn.Module):
         attention dropout (counter-based masks seeded from torch's CPU generator)."""
         x = data.x
         _lib.require_cuda(x, "data.x")
-        if self.residual_proj is not None:
-            raise NotImplementedError("training with residual_proj (input_dim != output_dim) is not supported")
         x = x.to(torch.float32).contiguous()
         csr = self._csr(data, use_edge_attr)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout > 0 else 0

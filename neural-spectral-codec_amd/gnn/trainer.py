@@ -58,8 +58,18 @@ class TripletLoss(nn.Module):
         """Fused gather + loss (+ gradient): embeddings (N,D), three index vectors (T,)."""
         _lib.require_cuda(embeddings, "embeddings")
         dev = embeddings.device
-        idx = [torch.as_tensor(np.asarray(i) if not isinstance(i, torch.Tensor) else i).to(
-            device=dev, dtype=torch.int64).contiguous() for i in (anchor_idx, positive_idx, negative_idx)]
+        n = int(embeddings.shape[0])
+        idx = []
+        for i in (anchor_idx, positive_idx, negative_idx):
+            if not (isinstance(i, torch.Tensor) and i.is_cuda):
+                # host-side indices (the miner's triplet list): embeddings[idx] would raise here in the reference
+                # (trainer.py:207-209).  Device-resident indices are checked by the kernel instead (an index
+                # outside [-N, N) turns the loss into NaN and writes nothing) -- no device sync on this path.
+                h = np.asarray(i.cpu() if isinstance(i, torch.Tensor) else i).astype(np.int64)
+                if h.size and (h.min() < -n or h.max() >= n):
+                    raise IndexError(f"triplet index out of range for {n} embeddings")
+                i = torch.from_numpy(h)
+            idx.append(i.to(device=dev, dtype=torch.int64).contiguous())
         return _TripletFn.apply(embeddings.float(), idx[0], idx[1], idx[2], self.margin, scale)
 
     def forward(self, anchors: torch.Tensor, positives: torch.Tensor, negatives: torch.Tensor) -> torch.Tensor:

@@ -143,17 +143,32 @@ def forward_from_state(sd, gnn_cfg, x, ei, ea, training=False):
     return out
 
 
-def forward_reference(model, data, training=False):
-    """src/gnn/model.py:96-153 with the module's own parameters, on the CPU in float32.
+def forward_reference(model, data, training=False, dtype=torch.float32):
+    """src/gnn/model.py:96-153 with the module's own parameters, on the CPU in float32 (the reference's
+    arithmetic) or, with dtype=torch.float64, the same restatement evaluated in double precision (the
+    checker for element-wise bounds: its own rounding error is negligible against the 1e-4 bar).
     training=True uses batch statistics in BatchNorm and NO dropout (dropout is stochastic and
     unseeded in the reference; parity runs use dropout=0)."""
     gnn = getattr(model, "gnn", model)                                  # LocalUpdateGNN wrapper :230
-    sd = {k: v.detach().cpu().float() for k, v in gnn.state_dict().items()}
-    x = data.x.detach().cpu().float()
+    sd = {k: (v.detach().cpu().to(dtype) if v.dtype.is_floating_point else v.detach().cpu())
+          for k, v in gnn.state_dict().items()}
+    x = data.x.detach().cpu().to(dtype)
     ei = data.edge_index.detach().cpu()
     ea = getattr(data, "edge_attr", None)
-    ea = ea.detach().cpu().float() if ea is not None else None
+    ea = ea.detach().cpu().to(dtype) if ea is not None else None
     return forward_from_state(sd, (gnn.n_layers, gnn.residual, gnn.edge_dim), x, ei, ea, training)
+
+
+def assert_within_bar(out, ref, rtol=1e-4, atol=1e-6, what="GAT output"):
+    """north_star bar for the GAT output, ELEMENT-WISE: |out - ref| <= rtol * |ref| + atol for every element."""
+    out, ref = out.detach().cpu().double(), ref.detach().cpu().double()
+    assert out.shape == ref.shape, f"{what}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    d = (out - ref).abs()
+    bound = rtol * ref.abs() + atol
+    worst = (d / bound).max().item() if d.numel() else 0.0
+    assert bool((d <= bound).all()), (f"{what}: {(d > bound).sum().item()} of {d.numel()} elements outside "
+                                      f"|d| <= {rtol}*|ref| + {atol} (worst {worst:.2f}x the bound, max |d| {d.max().item():.3g})")
+    return worst
 
 
 def reference_gradients(model, data, loss_fn):

@@ -20,8 +20,15 @@ from neural_spectral_codec_amd.keyframe import graph_manager as gm
 
 
 class OracleEncoder:
-    def encode_points_batch(self, clouds):
-        return torch.from_numpy(np.stack([orc.encode_points(c) for c in clouds]))
+    alpha = torch.tensor(2.0)            # .alpha.device is how the path finds the encoder's device
+    output_dim = 800
+
+    def encode_points_batch(self, clouds, out=None):
+        d = torch.from_numpy(np.stack([orc.encode_points(c) for c in clouds]))
+        if out is None:
+            return d
+        out.copy_(d)
+        return out
 
 
 class OracleGnn:
@@ -40,7 +47,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, n_total, pipeline, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,23 +56,39 @@ def _worker(rank, world, port, n_total, q):
         model = create_spectral_gnn(edge_dim=2).eval()
         go.randomize_bn_stats(model)
         poses = synth.make_pose_chain(n_total, 3)
-        path = nd.ShardedDescriptorPath(OracleEncoder(), OracleGnn(model), n_total, poses)
-        assert path.overlap == (n_total % world == 0)     # 24: boundary exchange + async all-gather; 21: plain
+        path = nd.ShardedDescriptorPath(OracleEncoder(), OracleGnn(model), n_total, poses, pipeline=pipeline)
+        # serial: 24 / 36 keyframes use the boundary exchange + async all-gather, 21 the padded all-gather;
+        # pipelined: one all-gather per step into the rotating slots
+        assert path.overlap == (n_total % world == 0 and not pipeline)
         lo, hi = path.lo, path.hi
         clouds = [synth.make_cloud(1000 + i, 1500, "uniform") for i in range(lo, hi)]
-        for _ in range(2):                                   # second step reuses the cached graph
-            desc_all, emb = path.step(clouds)
-        q.put((rank, lo, hi, desc_all.numpy(), emb.numpy()))
+        other = [synth.make_cloud(5000 + i, 700, "ring") for i in range(lo, hi)]
+        # more steps than rotating buffers; the batches alternate, so a result that a LATER step overwrote
+        # (a slot reused too early) would no longer equal the single-process result
+        n_steps = nd.ShardedDescriptorPath._PIPE_BUFFERS + 2 if pipeline else 3
+        kept = None
+        for k in range(n_steps):
+            res = path.step(clouds if k % 2 == 0 else other)
+            if k == n_steps - 2:
+                kept = res                                   # still valid one step later
+        path.synchronize()
+        last_is_clouds = (n_steps - 1) % 2 == 0
+        desc_all, emb = res if last_is_clouds else kept      # the newest result computed from `clouds`
+        if pipeline:                                         # (serial mode reuses ONE gathered buffer per step)
+            desc_other = (kept if last_is_clouds else res)[0]
+            assert not np.array_equal(desc_other.numpy(), desc_all.numpy())
+        q.put((rank, lo, hi, desc_all.numpy().copy(), emb.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,world", [(24, 2), (21, 2), (36, 3)])
-def test_multi_rank_gloo_matches_single_process(n_total, world):
+@pytest.mark.parametrize("n_total,world,pipeline", [(24, 2, False), (21, 2, False), (36, 3, False),
+                                                    (24, 2, True), (21, 2, True), (36, 3, True)])
+def test_multi_rank_gloo_matches_single_process(n_total, world, pipeline):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, pipeline, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])

@@ -83,6 +83,70 @@ def test_forward_train_and_gradients(n, edge_dim):
     assert int(m.gnn.input_norm.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("in_dim,out_dim,residual", [(800, 800, False), (64, 32, False), (32, 64, False),
+                                                     (64, 48, True), (48, 80, True)])
+def test_residual_variants_train(in_dim, out_dim, residual):
+    """SpectralGNN(residual=False) and residual_proj (input_dim != output_dim, model.py:91-94,147-149) through
+    forward_train / backward with x.requires_grad: the input gradient carries dOut only through an identity
+    residual, dOut W_res through residual_proj, and nothing when residual is off."""
+    from neural_spectral_codec_amd.gnn.model import SpectralGNN
+    n = 150
+    torch.manual_seed(4)
+    m = SpectralGNN(input_dim=in_dim, hidden_dim=64, output_dim=out_dim, n_layers=3, dropout=0.0,
+                    residual=residual, edge_dim=2)
+    go.randomize_bn_stats(m, 5)
+    assert (m.residual_proj is not None) == (residual and in_dim != out_dim)
+    m = m.to("cuda")
+    g = gm.synthetic_chain_graph(n, device="cuda", seed=8, features=torch.rand(n, in_dim))
+    R = torch.randn(n, out_dim, generator=torch.Generator().manual_seed(2))
+    emb_ref, grads_ref, gx_ref, _ = go.reference_gradients(m, g, lambda e: (e * R).sum() + (e * e).sum())
+    m.train()
+    g.x.requires_grad_(True)
+    emb = m(g)
+    ((emb * R.cuda()).sum() + (emb * emb).sum()).backward()
+    assert _rel(emb.detach().cpu(), emb_ref) < 1e-4
+    assert _rel(g.x.grad.cpu(), gx_ref) < 2e-3
+    params = dict(m.named_parameters())
+    keys = _key_map(m) + (["residual_proj.weight", "residual_proj.bias"] if m.residual_proj is not None else [])
+    gscale = max(v.abs().max().item() for v in grads_ref.values())
+    for k in keys:
+        got = params[k].grad.detach().cpu().reshape(grads_ref[k].shape)
+        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
+            assert got.abs().max().item() < 1e-3 * gscale, k
+            continue
+        assert _rel(got, grads_ref[k]) < 2e-3, k
+    # eval forward of the same shapes
+    m.eval()
+    with torch.no_grad():
+        go.assert_within_bar(m(g), go.forward_reference(m, g, dtype=torch.float64))
+
+
+def test_triplet_indices_follow_tensor_indexing():
+    """embeddings[idx] semantics (trainer.py:207-209): negative indices wrap; out of range raises on the host and,
+    for device-resident indices (no sync on that path), poisons the loss with NaN and writes nothing."""
+    torch.manual_seed(1)
+    n = 60
+    emb = torch.randn(n, 800, device="cuda", requires_grad=True)
+    crit = TripletLoss(0.1)
+    ia, ip, in_ = np.array([0, 5, 59, 7]), np.array([3, 9, 1, 8]), np.array([10, 20, 30, 40])
+    want = crit.forward_indexed(emb, ia, ip, in_)
+    got = crit.forward_indexed(emb, ia - n, ip, in_ - n)               # wrapped negatives
+    assert torch.equal(want, got)
+    with pytest.raises(IndexError):
+        crit.forward_indexed(emb, np.array([0, n]), np.array([1, 2]), np.array([3, 4]))
+    with pytest.raises(IndexError):
+        crit.forward_indexed(emb, np.array([0, 1]), np.array([1, -n - 1]), np.array([3, 4]))
+    bad = torch.tensor([0, n + 7], device="cuda")
+    ok = torch.tensor([1, 2], device="cuda")
+    loss = crit.forward_indexed(emb, bad, ok, ok + 5)
+    loss.backward()
+    assert torch.isnan(loss)
+    g = emb.grad.cpu()
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[[0, 1, 6]] = True                                            # the valid triplet (0, 1, 6)
+    assert torch.isfinite(g).all() and bool((g[~touched] == 0).all())    # the bad triplet wrote nothing
+
+
 def test_triplet_loss_matches_torch():
     torch.manual_seed(0)
     emb = torch.randn(500, 800, device="cuda", requires_grad=True)
@@ -124,6 +188,105 @@ def test_train_steps_reduce_loss_and_match_cpu_adam():
     got = dict(m2.gnn.named_parameters())
     for k in ("output_proj.weight", "convs.1.lin_src.weight", "input_proj.weight"):
         assert torch.allclose(got[k].detach().cpu(), params[k].detach(), rtol=1e-3, atol=2e-5), k
+
+
+def _config5_dataset(dev):
+    """BASELINE configs[4] shape: 15 synthetic sequences -- 9 "KITTI-like" + 6 "NCLT-like" -- 4 541 keyframes in
+    all, every sequence a closed course driven 2-3 times so that revisits (positives) exist; descriptors come from the
+    encoder on synthetic clouds whose scene depends on the PLACE, so revisits look alike."""
+    from neural_spectral_codec_amd.encoding import SpectralEncoder
+    from neural_spectral_codec_amd import synth
+    rng = np.random.default_rng(7)
+    kitti = [454, 110, 466, 80, 27, 276, 110, 110, 407]          # keyframes per sequence, sums to 2 040
+    nclt = [420, 415, 418, 412, 421, 415]                        # 2 501
+    lens = kitti + nclt
+    assert sum(lens) == 4541 and len(lens) == 15
+    poses, seq_ids, place = [], [], []
+    for s, ln in enumerate(lens):
+        laps = 2 if s < 9 else 3
+        per_lap = ln / laps
+        radius = per_lap * 1.2 / (2 * np.pi)                     # ~1.2 m between keyframes
+        t = np.arange(ln) / per_lap * 2 * np.pi
+        p = np.tile(np.eye(4), (ln, 1, 1))
+        p[:, 0, 3] = radius * np.cos(t) + rng.normal(0, 0.3, ln) + 1000.0 * s
+        p[:, 1, 3] = radius * np.sin(t) + rng.normal(0, 0.3, ln)
+        c, sn = np.cos(t + np.pi / 2), np.sin(t + np.pi / 2)
+        p[:, 0, 0], p[:, 0, 1], p[:, 1, 0], p[:, 1, 1] = c, -sn, sn, c
+        poses.append(p)
+        seq_ids += [s] * ln
+        place += list(100000 * s + np.floor((np.arange(ln) % per_lap) / 3).astype(int))    # 3 keyframes share a scene
+    poses = np.concatenate(poses)
+    enc = SpectralEncoder(n_elevation=16).to(dev)
+    pts, off = synth.make_clouds_packed(place, 3000, "ring")
+    desc = enc.encode_points_batch((torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev)))
+    return desc, poses, np.asarray(seq_ids)
+
+
+def test_config5_full_size_train_step():
+    """BASELINE configs[4] at its stated size on one GPU: a 4 541-keyframe chain graph over 15 synthetic KITTI+NCLT
+    sequences, triplets from the device miner, ONE 1 024-triplet batch through forward + TripletLoss + backward
+    (hidden_dim=256, margin=0.1, dropout 0 for parity): loss, every parameter gradient, the input gradient and one
+    Adam step against torch autograd through the restatement (reference src/gnn/trainer.py:186-221)."""
+    import copy
+    from neural_spectral_codec_amd.gnn.triplet_miner import create_triplet_miner
+    from neural_spectral_codec_amd.keyframe.graph_manager import build_chain_graph
+    dev = torch.device("cuda")
+    desc, poses, seq_ids = _config5_dataset(dev)
+    n = 4541
+    assert desc.shape == (n, 800)
+    graph = build_chain_graph(desc, 5, "cuda", poses)            # one chain across all sequences (SURVEY 9.2)
+    assert graph.edge_index.shape == (2, 18158) and graph.edge_attr.shape == (18158, 2)
+    np.random.seed(3)
+    trip_all = np.asarray(create_triplet_miner().mine_triplets(desc.cpu().numpy(), poses, 1, sequence_ids=seq_ids))
+    assert len(trip_all) >= 1024, f"only {len(trip_all)} triplets mined"
+    assert (seq_ids[trip_all[:, 0]] == seq_ids[trip_all[:, 1]]).all() and (seq_ids[trip_all[:, 0]] == seq_ids[trip_all[:, 2]]).all()
+    np.random.shuffle(trip_all)                                   # trainer.py:183
+    trip = trip_all[:1024]
+    tt = torch.from_numpy(trip)
+
+    torch.manual_seed(0)
+    m = create_spectral_gnn(input_dim=800, hidden_dim=256, output_dim=800, n_layers=3, dropout=0.0, edge_dim=2)
+    go.randomize_bn_stats(m, 1)
+    with torch.no_grad():
+        for c in m.gnn.convs:
+            c.bias.normal_(0, 0.1)
+    cpu_model = copy.deepcopy(m)
+    m = m.to(dev)
+    emb_ref, grads_ref, gx_ref, loss_ref = go.reference_gradients(
+        cpu_model, graph, lambda e: go.triplet_loss_reference(e, tt[:, 0], tt[:, 1], tt[:, 2], 0.1) / 4)
+
+    tr = GNNTrainer(m, device="cuda", learning_rate=5e-4, weight_decay=1e-5, margin=0.1, batch_size=1024,
+                    accumulation_steps=4)                          # train_multi_dataset.yaml:127-129, trainer.py:187-188
+    m.train()
+    tr.optimizer.zero_grad()
+    graph.x.requires_grad_(True)
+    emb = m(graph)                                                # trainer.py:205
+    loss = tr.criterion.forward_indexed(emb, trip[:, 0], trip[:, 1], trip[:, 2], scale=1.0 / 4)   # :207-212
+    loss.backward()                                               # :213
+    assert loss_ref.item() > 0
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 1e-7
+    go.assert_within_bar(emb, emb_ref, what="train-mode forward, 4 541 keyframes")
+    params = dict(m.gnn.named_parameters())
+    gscale = max(v.abs().max().item() for v in grads_ref.values())
+    for k in _key_map(m.gnn):
+        got = params[k].grad.detach().cpu().reshape(grads_ref[k].shape)
+        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
+            assert got.abs().max().item() < 1e-3 * gscale and grads_ref[k].abs().max().item() < 1e-3 * gscale, k
+            continue
+        assert _rel(got, grads_ref[k]) < 2e-3, k                  # float32 sums over 4 541 nodes, different order
+    assert _rel(graph.x.grad.cpu(), gx_ref) < 2e-3
+    # one Adam step (lr 5e-4, L2 weight decay 1e-5, trainer.py:115-119) on both sides
+    tr.optimizer.step()
+    cparams = dict(cpu_model.gnn.named_parameters())
+    opt = torch.optim.Adam(cpu_model.parameters(), lr=5e-4, weight_decay=1e-5)
+    for k, gr in grads_ref.items():
+        cparams[k].grad = gr.reshape(cparams[k].shape)
+    opt.step()
+    for k in _key_map(m.gnn):
+        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
+            continue          # zero-gradient parameters: Adam turns rounding noise into +-lr steps on either side
+        assert torch.allclose(params[k].detach().cpu().reshape(cparams[k].shape), cparams[k].detach(),
+                              rtol=1e-3, atol=2e-5), k
 
 
 def test_dropout_masks():

@@ -20,6 +20,8 @@
 // only where fma()/__builtin_fmaf is spelled out.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/nsc.h"
 #include "nsc_math.h"
@@ -40,8 +42,17 @@ struct EncDev {
     int E, R, B;
     float eps;
     int interp;
-    int dev_skip_finish;   // development knob (NSC_TUNE_SKIP_FINISH): time the scatter phase alone
+#ifdef NSC_DEV_TUNING
+    int dev_skip;          // development builds only (NSC_TUNE_SKIP_FINISH): phase masks for tools/ab_enc.py
+#endif
 };
+
+// Phase masks exist only in development builds (NSC_DEV_BUILD=1); the shipped kernels carry none of it.
+#ifdef NSC_DEV_TUNING
+#define NSC_DEV_SKIP(d, bit) (((d).dev_skip & (bit)) != 0)
+#else
+#define NSC_DEV_SKIP(d, bit) false
+#endif
 
 // exp(-2 pi i j / 360) = (cos, -sin): table holds (cos, sin)
 __device__ const double2 g_tw360[A] = {
@@ -101,26 +112,9 @@ __device__ __forceinline__ void scatter_point(float x, float y, float z, const N
 
 template <int NT, int U>
 __device__ __forceinline__ void scatter_range(const float *__restrict__ pts, long long p0, long long p1,
-                                              int stride, int tid, const NscBinParams &bp, unsigned *img,
-                                              int dev_loads_only = 0)
+                                              int stride, int tid, const NscBinParams &bp, unsigned *img)
 {
     const int n = (int)(p1 - p0);              // a cloud holds < 2^31 points
-    if (dev_loads_only) {      // development probe: the same loads, no binning / LDS atomics
-        const f32x4 *P = reinterpret_cast<const f32x4 *>(pts) + p0;
-        float s = 0.f;
-        for (int i = tid; i < n; i += NT * U) {
-            f32x4 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = i + u * NT;
-                v[u] = (j < n) ? __builtin_nontemporal_load(&P[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) s += v[u].x + v[u].y + v[u].z;
-        }
-        atomicMin(&img[tid & 63], __float_as_uint(fabsf(s)));
-        return;
-    }
     if (stride == 4) {
         const f32x4 *P = reinterpret_cast<const f32x4 *>(pts) + p0;
         for (int i = tid; i < n; i += NT * U) {
@@ -275,17 +269,22 @@ __device__ __forceinline__ void dft5(double (&re)[5], double (&im)[5])
     re[3] = m2r - n2i; im[3] = m2i + n2r;              // m2 + i n2
 }
 
-__device__ __forceinline__ void fft_row(const float *x, double2 *buf, const double2 *tw, float *mags,
-                                        int lane)
+// stage-1 operands of one row: lane j < 45 holds z[j + 45 r] = (x[2(j+45r)], x[2(j+45r)+1]), r = 0..3
+__device__ __forceinline__ void fft_load_row(const float *x, int lane, f32x2 (&in)[4])
 {
-    {   // stage 1: R = 4, Ns = 1, 45 butterflies, input straight from the float32 image row
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        in[r] = (lane < 45) ? *reinterpret_cast<const f32x2 *>(&x[2 * (lane + 45 * r)]) : f32x2{0.f, 0.f};
+}
+
+__device__ __forceinline__ void fft_row_regs(const f32x2 (&in)[4], double2 *buf, const double2 *tw, float *mags,
+                                             int lane)
+{
+    {   // stage 1: R = 4, Ns = 1, 45 butterflies, input = the float32 image row (held in registers)
         double re[4], im[4];
         if (lane < 45) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x2 v = *reinterpret_cast<const f32x2 *>(&x[2 * (lane + 45 * r)]);
-                re[r] = (double)v.x; im[r] = (double)v.y;
-            }
+            for (int r = 0; r < 4; ++r) { re[r] = (double)in[r].x; im[r] = (double)in[r].y; }
             dft4(re, im);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[4 * lane + q] = o; }
@@ -376,6 +375,13 @@ __device__ __forceinline__ void fft_row(const float *x, double2 *buf, const doub
         }
     }
     wave_sync();
+}
+
+__device__ __forceinline__ void fft_row(const float *x, double2 *buf, const double2 *tw, float *mags, int lane)
+{
+    f32x2 in[4];
+    fft_load_row(x, lane, in);
+    fft_row_regs(in, buf, tw, mags, lane);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -498,15 +504,12 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
         rows = pool;
         __syncthreads();
     }
-    if (d.dev_skip_finish & 16) return;
-
     for (int r = wave; r < R; r += NW) {
         float *row = rows + r * A;
         float *mags = row;                                        // the row is dead after FFT stage 1
         float *hist = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(row) + HIST_OFF);
-        if (!(d.dev_skip_finish & 4)) fft_row(row, fftbuf, tw, mags, lane);
+        fft_row(row, fftbuf, tw, mags, lane);
         double part = 0.0;
-        if (!(d.dev_skip_finish & 8))
         for (int b = lane; b < B; b += 64) {
             float h = 0.0f;
             const int k1 = seg[B + b];
@@ -560,16 +563,335 @@ __global__ __launch_bounds__(NW * 64, MINW) void encode_fused_kernel(
     for (int i = tid; i < npix; i += NT) img[i] = NSC_EMPTY_BITS;  // :205 full(inf)
     __syncthreads();
     if (tid >= NT - 64) setup_tables<NW>(lds, d, lut, tid - (NT - 64), 64);   // last wave; joins the stream late
-    scatter_range<NT, U>(pts, off[c], off[c + 1], stride, tid, d.bp, img, d.dev_skip_finish & 32);
+    scatter_range<NT, U>(pts, off[c], off[c + 1], stride, tid, d.bp, img);
     __syncthreads();
-    if (d.dev_skip_finish & 1) {
-        if (tid == 0) out_desc[(long long)c * d.R * d.B] = __uint_as_float(img[0]);
-        return;
-    }
     const long long D = (long long)d.R * d.B;
     finish_image<NW>(lds, d, 0, out_desc + c * D,
                      out_raw ? out_raw + (long long)c * npix : nullptr,
                      out_interp ? out_interp + (long long)c * npix : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode_fast_kernel -- the configuration every caller of the reference uses (16 x 360 image, no
+// pooling, (N,4) points, default FOV and range window), one 4-wave workgroup per cloud.
+//   stream   each lane keeps U 16-byte non-temporal loads in flight as a ROLLING window (a slot is refilled the
+//            moment its point has been copied out), bins with nsc_point_lean (~50 VALU instructions per point)
+//            and updates the LDS image with ds_min_u32.  A point whose estimate sits within the margin of a bin
+//            edge (~2e-4 of them) is not resolved in the loop -- that would drag all 64 lanes through two
+//            float64 atan2 -- but parked in an LDS queue;
+//   drain    the queue is resolved with the exact chain, compacted (a few dozen points per cloud);
+//   finish   as finish_image(), with the rows owned in contiguous blocks of four per wave so that the FFT
+//            scratch, the magnitudes and the histograms live in the wave's own (by then consumed) image rows.
+// LDS: image 23 040 + queue/twiddles 3 840 + segments + misc = 27.9 KB (the generic kernel: 39.4 KB) -- a resident
+// 1 024-cloud grid leaves 48 KB of every CU to whatever runs beside it.
+// ---------------------------------------------------------------------------------------------
+constexpr int FQ_CAP = TW_N;               // 240 queue entries of 16 B in the bytes the twiddle table occupies later
+constexpr int FAST_HSTRIDE = 64;           // floats between the histograms of a wave's four rows (n_bins <= 64)
+constexpr long long FAST_MAX_POINTS = 1LL << 27;   // per cloud: byte offsets stay below 2^31
+
+struct FastLds {
+    int img, aux, seg, misc, total;
+};
+
+__host__ __device__ inline FastLds fast_lds(int B)
+{
+    FastLds p;
+    int o = 0;
+    p.img = o;  o += 16 * ROW_BYTES;
+    p.aux = o;  o += TW_N * 16;                         // stream: uncertain-point queue; finish: twiddles
+    p.seg = o;  o += ((2 * B * 4) + 15) & ~15;
+    p.misc = o; o += MAXR * 8 + 16 * 4 + 16 * 4 + 16;   // rowsum f64[16], rowflag int[16], rowsrc int[16], qcount
+    p.total = o;
+    return p;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// The stream.  P = first point of the cloud, n > 0 points.  Each lane owns the points tid, tid + NT, ... and keeps
+// U 16-byte non-temporal loads in flight as a ROLLING window: slot u of round r holds point tid + (r U + u) NT; at
+// its turn the lane waits for exactly that load (s_waitcnt vmcnt(U - 1): loads return in order), bins the point and
+// refills the slot with the point U NT further on -- U - 1 loads are in flight while a point is binned, across
+// rounds too.
+//
+// The loads and their waits are inline asm: hipcc's own s_waitcnt insertion puts vmcnt(0) at the head of such a loop
+// (every round would start with the full latency of the load issued just before the back edge) and hoists the
+// squares of all U points to the top of a round.  Rules kept here (cdna_hip_programming.md 5.7): a slot is one
+// "+v" operand of BOTH statements, so the compiler holds it in one register quad and never reads it between the load
+// and the wait; every statement is volatile with a memory clobber (program order is kept); the last round issues no
+// loads and counts its waits down to vmcnt(0), so nothing is in flight when the registers are reused.
+template <int NT, int U>
+__device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, int tid, const NscBinParams &bp,
+                                            unsigned *img, f32x4 *queue, unsigned *qcount, int dev_mode = 0)
+{
+#ifdef NSC_DEV_TUNING
+    float dev_acc = 0.f;
+#endif
+    auto process = [&](const f32x4 &v) {
+#ifdef NSC_DEV_TUNING
+        if (dev_mode & 64) { dev_acc += v.x + v.y + v.z; return; }           // loads only
+#endif
+        int pix; float s; bool certain;
+        if (!nsc_point_lean_flags(v.x, v.y, v.z, bp, pix, s, certain)) return;
+#ifdef NSC_DEV_TUNING
+        if (dev_mode & 128) { dev_acc += (float)(pix + (int)certain) + s; return; }   // loads + binning, no LDS atomics
+#endif
+        if (certain) {
+            atomicMin(&img[pix], __float_as_uint(s));                // ds_min_u32 (s >= 0: uint order == float order)
+        } else {                                                     // ~2e-4 of the points
+            const unsigned slot = atomicAdd(qcount, 1u);             // counts past FQ_CAP: the kernel then re-streams
+            if (slot < (unsigned)FQ_CAP) queue[slot] = f32x4{v.x, v.y, v.z, s};
+        }
+    };
+    // wave-uniform base address in SGPRs + a 32-bit byte offset per lane (clouds hold < 2^27 points)
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(P);
+    const unsigned long long Pb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
+    const unsigned last = (unsigned)(n - 1) * 16u;                  // loads past the cloud re-read its last point
+    const int T = (n + NT * U - 1) / (NT * U);                      // rounds, the last one possibly partial
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the operands are local references: clang does not capture a variable that only an asm operand names)
+#define NSC_SLOT_LOAD(slot, ofs)                                                                                  \
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(slot) : "v"(ofs), "s"(base_) : "memory")
+#define NSC_SLOT_WAIT(slot, cnt) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "i"(cnt) : "memory")
+
+    unsigned o = (unsigned)tid * 16u;                               // byte offset of slot 0 of the current round
+    static_for<U>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        f32x4 &slot = buf[u];
+        const unsigned long long base_ = Pb;
+        const unsigned a = min(o + (unsigned)(u * NT * 16), last);
+        if (u == 0) asm volatile("s_nop 4" ::: "memory");           // readfirstlane -> SGPR base of a VMEM (hazard)
+        NSC_SLOT_LOAD(slot, a);
+    });
+    constexpr unsigned RB = (unsigned)(U * NT * 16);                 // bytes per round
+    for (int r = 0; r + 2 < T; ++r) {            // rounds whose refill (round r + 1) is complete: no clamping
+        static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            f32x4 &slot = buf[u];
+            const unsigned long long base_ = Pb;
+            NSC_SLOT_WAIT(slot, U - 1);
+            process(slot);
+            const unsigned a = o + RB + (unsigned)(u * NT * 16);
+            NSC_SLOT_LOAD(slot, a);
+        });
+        o += RB;
+    }
+    if (T >= 2) {                                // round T - 2: its refill is the last, possibly partial, round
+        static_for<U>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            f32x4 &slot = buf[u];
+            const unsigned long long base_ = Pb;
+            NSC_SLOT_WAIT(slot, U - 1);
+            process(slot);
+            const unsigned a = min(o + RB + (unsigned)(u * NT * 16), last);
+            NSC_SLOT_LOAD(slot, a);
+        });
+        o += RB;
+    }
+    static_for<U>([&](auto uc) {                 // last round: no refills, waits count down to vmcnt(0)
+        constexpr int u = decltype(uc)::value;
+        f32x4 &slot = buf[u];
+        NSC_SLOT_WAIT(slot, U - 1 - u);
+        f32x4 v = slot;
+        if (o + (unsigned)(u * NT * 16) > last) v.x = NAN;          // past the cloud: fails the range window
+        process(v);
+    });
+#undef NSC_SLOT_LOAD
+#undef NSC_SLOT_WAIT
+#ifdef NSC_DEV_TUNING
+    if (dev_mode & (64 | 128)) atomicMin(&img[tid & 63], __float_as_uint(fabsf(dev_acc)));
+#endif
+}
+
+__device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d, float *__restrict__ out_desc,
+                                            float *__restrict__ out_raw, float *__restrict__ out_interp)
+{
+    constexpr int NW = 4, NT = 256, E = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = d.B;
+    const FastLds lp = fast_lds(B);
+    float *img = reinterpret_cast<float *>(lds + lp.img);
+    double2 *tw = reinterpret_cast<double2 *>(lds + lp.aux);
+    const int *seg = reinterpret_cast<const int *>(lds + lp.seg);
+    double *rowsum = reinterpret_cast<double *>(lds + lp.misc);
+    int *rowflag = reinterpret_cast<int *>(lds + lp.misc + MAXR * 8);
+    int *rowsrc = rowflag + 16;
+
+    // the twiddle table replaces the (drained) queue; its global loads land under the sqrt / interpolation below
+    double2 twv = {0.0, 0.0};
+    if (tid < TW_N) twv = g_tw360[tid];
+
+    const int r0 = 4 * wave;                                      // this wave owns rows r0 .. r0 + 3
+    for (int r = r0; r < r0 + 4; ++r) {
+        float *row = img + r * A;
+        const unsigned *raw = reinterpret_cast<const unsigned *>(row);
+        float *graw = out_raw ? out_raw + r * A : nullptr;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int c = lane + 64 * j;
+            if (c < A) {
+                const unsigned v = raw[c];
+                const float rr = (v == NSC_EMPTY_BITS) ? 0.0f : sqrtf(__uint_as_float(v));   // :162,:214
+                row[c] = rr;
+                if (graw) graw[c] = rr;
+            }
+        }
+        wave_sync();
+        const int nv = interp_row(row, lane, d.interp != 0);
+        if (lane == 0) rowflag[r] = (nv > 0);
+    }
+    if (tid < TW_N) tw[tid] = twv;
+    __syncthreads();
+    if (d.interp) {                                               // range_image.py:77-87
+        unsigned ne = 0u;
+        for (int r = 0; r < E; ++r) ne |= (unsigned)(rowflag[r] != 0) << r;
+        if (ne != 0xffffu && ne != 0u) {                          // some (not all) rows are empty: rare
+            if (tid == 0) {
+                unsigned m = ne;
+                for (int r = 0; r < E; ++r) rowsrc[r] = r;
+                for (int r = 0; r < E; ++r) {
+                    if ((m >> r) & 1u) continue;
+                    for (int k = 1; k < E; ++k) {
+                        if (r - k >= 0 && ((m >> (r - k)) & 1u)) { rowsrc[r] = rowsrc[r - k]; m |= 1u << r; break; }
+                        if (r + k < E && ((m >> (r + k)) & 1u)) { rowsrc[r] = r + k; m |= 1u << r; break; }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int r = r0; r < r0 + 4; ++r) {
+                const int sr = rowsrc[r];                         // always an original (never copied) row
+                if (sr != r)
+                    for (int c = lane; c < A; c += 64) img[r * A + c] = img[sr * A + c];
+            }
+            __syncthreads();
+        }
+    }
+    if (out_interp)
+        for (int r = r0; r < r0 + 4; ++r)
+            for (int c = lane; c < A; c += 64) out_interp[r * A + c] = img[r * A + c];
+    if (NSC_DEV_SKIP(d, 16)) return;
+
+    // spectrum + histogram.  All four rows' stage-1 operands go to registers first; from then on the wave's 5 760
+    // image bytes are free: rows r0+1, r0+2 = FFT scratch (180 double2), row r0+3 = |X| (181 floats),
+    // row r0 = the four histograms (FAST_HSTRIDE floats apart).
+    f32x2 in[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fft_load_row(img + (r0 + q) * A, lane, in[q]);
+    wave_sync();
+    double2 *fftbuf = reinterpret_cast<double2 *>(img + (r0 + 1) * A);
+    float *mags = img + (r0 + 3) * A;
+    float *hist0 = img + r0 * A;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!NSC_DEV_SKIP(d, 4)) fft_row_regs(in[q], fftbuf, tw, mags, lane);
+        double part = 0.0;
+        if (!NSC_DEV_SKIP(d, 8))
+        for (int b = lane; b < B; b += 64) {
+            float h = 0.0f;
+            const int k1 = seg[B + b];
+            for (int k = seg[b]; k < k1; k += 8) {               // scatter_add_, ascending k (:152-155)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (k + u < k1) ? mags[k + u] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h += v[u];            // h + 0.0f == h: order and rounding unchanged
+            }
+            hist0[FAST_HSTRIDE * q + b] = h;
+            part += (double)h;
+        }
+        part = wave_sum(part);
+        if (lane == 0) rowsum[r0 + q] = part;
+        wave_sync();                                              // mags / scratch are rewritten by the next row
+    }
+    __syncthreads();
+
+    double tot = 0.0;
+    for (int r = 0; r < E; ++r) tot += rowsum[r];
+    const float s = (float)tot;                                   // :197
+    const int D = E * B;
+    if (s > d.eps) {
+        const float den = s + d.eps;                              // :199
+        for (int i = tid; i < D; i += NT) {
+            const int r = i / B, b = i - r * B;
+            out_desc[i] = img[(r & ~3) * A + FAST_HSTRIDE * (r & 3) + b] / den;
+        }
+    } else {
+        const float u = 1.0f / (float)D;                          // :202
+        for (int i = tid; i < D; i += NT) out_desc[i] = u;
+    }
+}
+
+template <int U>
+__global__ __launch_bounds__(256, 4) void encode_fast_kernel(
+    const float *__restrict__ pts, const long long *__restrict__ off, EncDev d, const int *__restrict__ lut,
+    float *__restrict__ out_desc, float *__restrict__ out_raw, float *__restrict__ out_interp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int NT = 256;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const FastLds lp = fast_lds(d.B);
+    unsigned *img = reinterpret_cast<unsigned *>(lds + lp.img);
+    f32x4 *queue = reinterpret_cast<f32x4 *>(lds + lp.aux);
+    unsigned *qcount = reinterpret_cast<unsigned *>(lds + lp.misc + MAXR * 8 + 32 * 4);
+    {
+        const uint4 e4 = {NSC_EMPTY_BITS, NSC_EMPTY_BITS, NSC_EMPTY_BITS, NSC_EMPTY_BITS};   // :205 full(inf)
+        uint4 *i4 = reinterpret_cast<uint4 *>(img);
+        for (int i = tid; i < 16 * A / 4; i += NT) i4[i] = e4;
+        if (tid == 0) *qcount = 0u;
+    }
+    __syncthreads();
+    if (tid >= NT - 64) {                    // last wave: histogram segments (see setup_tables), then joins the stream
+        int *seg = reinterpret_cast<int *>(lds + lp.seg);
+        const int B = d.B;
+        for (int b = tid - (NT - 64); b < 2 * B; b += 64) {
+            const int key = (b < B) ? b : b - B + 1;
+            int l = 0, h = F;
+            while (l < h) { const int m = (l + h) >> 1; if (lut[m] >= key) h = m; else l = m + 1; }
+            seg[b] = l;
+        }
+    }
+    const long long p0 = off[c];
+    const int n = (int)(off[c + 1] - p0);                           // < 2^27 (host check)
+    if (n > 0 && !NSC_DEV_SKIP(d, 2))
+#ifdef NSC_DEV_TUNING
+        stream_fast<NT, U>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount, d.dev_skip);
+#else
+        stream_fast<NT, U>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount);
+#endif
+    __syncthreads();
+    {   // drain the uncertain-point queue with the exact chain (the definition of the pixel), compacted
+        const unsigned qn = *qcount;
+        if (qn <= (unsigned)FQ_CAP) {
+            for (unsigned i = tid; i < qn; i += NT) {
+                const f32x4 e = queue[i];
+                atomicMin(&img[nsc_point_exact(e.x, e.y, e.z, d.bp)], __float_as_uint(e.w));
+            }
+        } else {
+            // More uncertain points than the queue holds (an adversarial cloud parked on bin edges): some were not
+            // recorded.  Stream the cloud again with the generic per-point path, which resolves them in place; min
+            // is idempotent, so the pixels already written stay right.
+            scatter_range<NT, 4>(pts, p0, p0 + n, 4, tid, d.bp, img);
+        }
+    }
+    __syncthreads();
+    if (NSC_DEV_SKIP(d, 1)) {
+        if (tid == 0) out_desc[(long long)c * 16 * d.B] = __uint_as_float(img[0]);
+        return;
+    }
+    const long long D = 16LL * d.B;
+    finish_fast(lds, d, out_desc + c * D, out_raw ? out_raw + (long long)c * 16 * A : nullptr,
+                out_interp ? out_interp + (long long)c * 16 * A : nullptr);
 }
 
 template <int NW, int U>
@@ -673,13 +995,20 @@ __global__ __launch_bounds__(256) void intensity_kernel(const float *__restrict_
 }
 
 __global__ __launch_bounds__(256) void point_bins_kernel(
-    const float *__restrict__ pts, long long n, int stride, NscBinParams bp,
+    const float *__restrict__ pts, long long n, int stride, NscBinParams bp, int lean,
     int *__restrict__ out_idx, unsigned char *__restrict__ out_flags)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const float x = pts[i * stride], y = pts[i * stride + 1], z = pts[i * stride + 2];
         int pix; float s;
+        if (lean) {            // what encode_fast_kernel does with a point: lean estimate, exact chain when uncertain
+            const int st = nsc_point_lean(x, y, z, bp, pix, s);
+            if (st == 2) pix = nsc_point_exact(x, y, z, bp);
+            out_idx[i] = st ? pix : -1;
+            if (out_flags) out_flags[i] = (unsigned char)(st == 2 ? 3 : 0);
+            continue;
+        }
         const int fl = nsc_point_pixel(x, y, z, bp, pix, s);
         out_idx[i] = fl ? pix : -1;
         if (out_flags) out_flags[i] = (unsigned char)(fl >> 1);
@@ -728,7 +1057,9 @@ EncDev make_dev(const NscEncParams *p, int rows_in)
     d.B = p->n_bins;
     d.eps = p->epsilon;
     d.interp = p->interpolate;
-    d.dev_skip_finish = tune_env("NSC_TUNE_SKIP_FINISH", 0);
+#ifdef NSC_DEV_TUNING
+    d.dev_skip = tune_env("NSC_TUNE_SKIP_FINISH", 0);
+#endif
     return d;
 }
 
@@ -814,6 +1145,24 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
 
     if (parts <= 1) {
         const int variant = tune_env("NSC_TUNE_VARIANT", 0);
+        // the configuration of every reference caller: the lean streaming kernel
+        if (variant <= 0 && stride == 4 && d.E == 16 && d.R == 16 && d.B <= FAST_HSTRIDE && nsc_lean_ok(d.bp) &&
+            total_points < FAST_MAX_POINTS) {
+            const FastLds fl = fast_lds(d.B);
+            if (variant == -1)
+                hipLaunchKernelGGL(encode_fast_kernel<4>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
+                                   out_desc, out_raw, out_interp);
+            else if (variant == -2)
+                hipLaunchKernelGGL(encode_fast_kernel<16>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
+                                   out_desc, out_raw, out_interp);
+            else if (variant == -3)
+                hipLaunchKernelGGL(encode_fast_kernel<12>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
+                                   out_desc, out_raw, out_interp);
+            else
+                hipLaunchKernelGGL(encode_fast_kernel<8>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
+                                   out_desc, out_raw, out_interp);
+            return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+        }
 #define NSC_LAUNCH_FUSED(NW_, U_, MINW_)                                                              \
     {                                                                                                 \
         auto k = encode_fused_kernel<NW_, U_, MINW_>;                                                 \
@@ -983,8 +1332,8 @@ int nsc_debug_point_bins(const float *pts, int64_t n_points, int32_t stride, con
     long long blocks = (n_points + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(point_bins_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream_), pts, (long long)n_points, stride, d.bp, out_idx,
-                       out_flags);
+                       static_cast<hipStream_t>(stream_), pts, (long long)n_points, stride, d.bp,
+                       (int)(stride == 4 && d.E == 16 && nsc_lean_ok(d.bp)), out_idx, out_flags);
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

@@ -222,6 +222,107 @@ NSC_HD int nsc_point_pixel(float x, float y, float z, const NscBinParams &bp, in
     return flags;
 }
 
+// ---- lean estimate (the streaming loop of encode_fast_kernel) ----------------------------------
+// Same definition, same polynomials and margins as above, arranged for the fewest VALU instructions:
+//   * the 180/pi of the column estimate is folded into the polynomial coefficients;
+//   * "f in (d, 1-d)" is one compare, |f - 1/2| < 1/2 - d (f - 1/2 rounds by <= 2^-26: covered by NSC_LEAN_GUARD);
+//   * rows beyond the FOV are made certain by clamping the row coordinate to [-1/2, E + 1/2] (f = 1/2 there);
+//   * no NaN reaches the row estimate: x = y = z = 0 fails the range window, which requires s_lo > 0.
+// Valid only for bp.simple_valid && bp.narrow_fov && bp.s_lo > 0 (nsc_lean_ok); everything else runs
+// nsc_point_pixel.  Returns 0 = dropped, 1 = (pix, s) certain, 2 = uncertain: the caller resolves the point with
+// nsc_point_exact (the kernel parks it in an LDS queue and resolves the queue after the stream).
+#define NSC_LEAN_GUARD 2.0e-7f
+
+NSC_HD float nsc_clampf(float v, float lo, float hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(v, lo, hi);          // v_med3_f32 (no NaN reaches it, see above)
+#else
+    return fminf(fmaxf(v, lo), hi);
+#endif
+}
+
+// atan(t) * 180/pi for t in [0,1]: the coefficients of nsc_atan01 times 57.29577951308232, rounded to float32
+NSC_HD float nsc_atan01_deg(float t)
+{
+    const float w = t * t;
+    float p = -2.3230952024e-01f;
+    p = __builtin_fmaf(p, w, 1.2526550293e+00f);
+    p = __builtin_fmaf(p, w, -3.2035398483e+00f);
+    p = __builtin_fmaf(p, w, 5.5245718956e+00f);
+    p = __builtin_fmaf(p, w, -7.9690575600e+00f);
+    p = __builtin_fmaf(p, w, 1.1428540230e+01f);
+    p = __builtin_fmaf(p, w, -1.9096603394e+01f);
+    p = __builtin_fmaf(p, w, 5.7295742035e+01f);
+    return p * t;
+}
+
+NSC_HD bool nsc_lean_ok(const NscBinParams &bp) { return bp.simple_valid && bp.narrow_fov && bp.s_lo > 0.0f; }
+
+NSC_HD float nsc_fractf(float v)          // v - floor(v), in [0, 1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fractf(v);                  // v_fract_f32
+#else
+    const float f = v - floorf(v);
+    return f < 1.0f ? f : 0x1.fffffep-1f;               // v_fract_f32 clamps below 1
+#endif
+}
+
+NSC_HD int nsc_mul24(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);                               // v_mul_i32_i24: full rate (v_mul_lo_u32 is quarter rate)
+#else
+    return a * b;
+#endif
+}
+
+// Returns false if the point is dropped; else `certain` says whether (pix, s) is final or pix only the estimate.
+NSC_HD bool nsc_point_lean_flags(float x, float y, float z, const NscBinParams &bp, int &pix, float &s, bool &certain)
+{
+    const float sxy = x * x + y * y;
+    s = sxy + z * z;
+    certain = false;
+    if (!(s >= bp.s_lo && s <= bp.s_hi)) return false;                // :151-155, :174-177 (inf/NaN fall out here)
+    // column: octant reduction + degree-7 minimax atan, in columns
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float q = nsc_atan01_deg(mn * nsc_rcp_approx(mx));          // [0,45]; NaN for x = y = 0 -> uncertain
+    const float gc = nsc_fractf(q) - 0.5f;
+    const int iq = (int)q;                                            // q >= 0: truncation == floor
+    int ib = (ax >= ay) ? iq : 89 - iq;
+    ib = (x < 0.0f) ? 179 - ib : ib;
+    const int col = (y < 0.0f) ? 179 - ib : 180 + ib;
+    const bool cok = fabsf(gc) < (0.5f - NSC_LEAN_GUARD) - bp.az_delta;
+    // row: t = z / rxy from v_rsq_f32, degree-5 atan, affine map to rows, clamp so that out-of-FOV rows are certain
+    const float t = nsc_clampf(z * nsc_rsq_approx(sxy), -0.62f, 0.62f);
+    const float u = nsc_clampf(__builtin_fmaf(nsc_atan_small(t), bp.el_u_scale, bp.el_u_bias), -0.5f,
+                               (float)bp.E + 0.5f);
+    const float gr = nsc_fractf(u) - 0.5f;
+    int row = (int)u;                                                 // u in [-0.5, E + 0.5]: (-0.5, 0) truncates to row 0
+    row = row > bp.E - 1 ? bp.E - 1 : row;
+    const bool rok = fabsf(gr) < (0.5f - NSC_LEAN_GUARD) - bp.el_delta;
+    pix = nsc_mul24(row, NSC_A) + col;
+    certain = cok && rok;
+    return true;
+}
+
+// 0 = dropped, 1 = (pix, s) certain, 2 = uncertain (host-side checks)
+NSC_HD int nsc_point_lean(float x, float y, float z, const NscBinParams &bp, int &pix, float &s)
+{
+    bool certain;
+    if (!nsc_point_lean_flags(x, y, z, bp, pix, s, certain)) return 0;
+    return certain ? 1 : 2;
+}
+
+// Exact chain for a point that passed the range window (the definition of the pixel).
+NSC_HD int nsc_point_exact(float x, float y, float z, const NscBinParams &bp)
+{
+    const float sxy = nsc_clip_sq(x) + nsc_clip_sq(y);
+    return nsc_row_exact(z, sxy, bp) * NSC_A + nsc_col_exact(y, x);
+}
+
 // ---- host-side setup (plain C++, also used by the CPU margin tests) ---------------------------
 // (host functions: hipcc's device pass parses but never emits them)
 

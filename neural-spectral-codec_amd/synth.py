@@ -80,16 +80,59 @@ def make_clouds_packed(seeds, n_points=120000, kind="uniform"):
     return (np.concatenate(clouds, 0) if clouds else np.zeros((0, 4), np.float32)), offsets
 
 
-def make_clouds_device(n_clouds, n_points, device, seed=0):
-    """Batch of 'uniform' clouds generated directly in HBM with torch (bench workload: 1 024 x 120 k
-    points = 1.97 GB never crosses PCIe).  Not bit-reproducible against make_cloud(); parity checks
-    on bench data copy a sample of clouds back to the host and feed the same bits to the oracle."""
+def make_clouds_device(n_clouds, n_points, device, seed=0, order="uniform"):
+    """Batch of clouds generated directly in HBM with torch (bench workload: 1 024 x 120 k points = 1.97 GB never
+    crosses PCIe).  Not bit-reproducible against make_cloud(); parity checks on bench data copy a sample of clouds
+    back to the host and feed the same bits to the oracle.
+
+    order: 'uniform'        az, el, r i.i.d. uniform, points in random order (the friendly case for the LDS image)
+           'azimuth_major'  HDL-64-like sensor order: 64 lasers fire at one azimuth, then the head turns -- 64
+                            consecutive points share a column, every 4 of them a pixel (SURVEY section 7's hazard)
+           'ring_major'     the same scan sorted by laser: one ring's whole revolution is contiguous -- ~5 consecutive
+                            points per pixel, a wave's 64 points fall on ~12 neighbouring pixels of ONE row
+    The scans carry a smooth place-dependent range profile and 5 % dropouts (holes for the interpolation)."""
     import math
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     pts = torch.empty((n_clouds * n_points, 4), dtype=torch.float32, device=device)
     chunk = max(1, (1 << 24) // max(n_points, 1))
+    if order != "uniform":
+        if order not in ("azimuth_major", "ring_major"):
+            raise ValueError(order)
+        rings = 64
+        steps = n_points // rings
+        assert steps * rings == n_points, "n_points must be a multiple of 64 for sensor-ordered clouds"
+        for c0 in range(0, n_clouds, chunk):
+            c1 = min(n_clouds, c0 + chunk)
+            nc = c1 - c0
+            if order == "azimuth_major":
+                st = torch.arange(steps, device=device, dtype=torch.float32).view(1, steps, 1)
+                rg = torch.arange(rings, device=device, dtype=torch.float32).view(1, 1, rings)
+                shape = (nc, steps, rings)
+            else:
+                st = torch.arange(steps, device=device, dtype=torch.float32).view(1, 1, steps)
+                rg = torch.arange(rings, device=device, dtype=torch.float32).view(1, rings, 1)
+                shape = (nc, rings, steps)
+            ph = torch.rand((nc, 3), generator=g, device=device, dtype=torch.float32) * (2 * math.pi)
+            ph = ph.view(nc, 3, 1, 1)
+            noise = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+            az = -math.pi + st * (2 * math.pi / steps) + noise * 2e-4
+            noise = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+            el = (-24.6 + rg * (26.5 / (rings - 1))) * (math.pi / 180.0) + noise * 2e-4
+            r = (25.0 + 12.0 * torch.sin(2 * az + ph[:, 0]) + 6.0 * torch.sin(5 * az + ph[:, 1])
+                 + 3.0 * torch.sin(11 * az + ph[:, 2]) + 20.0 * rg / rings)
+            drop = torch.rand(shape, generator=g, device=device, dtype=torch.float32) < 0.05
+            r = torch.where(drop, torch.full_like(r, 0.2), r)            # below min_range: filtered out
+            ce = torch.cos(el)
+            blk = pts[c0 * n_points:c1 * n_points]
+            blk[:, 0] = (r * ce * torch.cos(az)).reshape(-1)
+            blk[:, 1] = (r * ce * torch.sin(az)).reshape(-1)
+            blk[:, 2] = (r * torch.sin(el)).reshape(-1)
+            blk[:, 3] = torch.rand(nc * n_points, generator=g, device=device, dtype=torch.float32)
+            del az, el, r, ce, noise, drop
+        offsets = torch.arange(0, n_clouds + 1, dtype=torch.int64, device=device) * n_points
+        return pts, offsets
     for c0 in range(0, n_clouds, chunk):
         c1 = min(n_clouds, c0 + chunk)
         m = (c1 - c0) * n_points

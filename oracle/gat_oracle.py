@@ -171,22 +171,24 @@ def assert_within_bar(out, ref, rtol=1e-4, atol=1e-6, what="GAT output"):
     return worst
 
 
-def reference_gradients(model, data, loss_fn):
+def reference_gradients(model, data, loss_fn, dtype=torch.float32):
     """Reference gradients by torch autograd through the restatement (train-mode BatchNorm, no
-    dropout).  loss_fn(embeddings) -> scalar.  Returns (embeddings, {state-dict key: grad}, grad_x)."""
+    dropout).  loss_fn(embeddings) -> scalar.  Returns (embeddings, {state-dict key: grad}, grad_x, loss).
+    dtype=torch.float64 evaluates the same restatement in double precision (used to measure how far float32
+    arithmetic itself sits from the exact result on ill-conditioned inputs)."""
     gnn = getattr(model, "gnn", model)
     sd = {}
     for k, v in gnn.state_dict().items():
-        t = v.detach().cpu().float().clone()
+        t = v.detach().cpu().to(dtype).clone() if v.dtype.is_floating_point else v.detach().cpu().clone()
         if v.dtype.is_floating_point and "running_" not in k:
             t.requires_grad_(True)
         sd[k] = t
     for l in range(gnn.n_layers):                       # lin_dst aliases lin_src (one parameter)
         sd[f"convs.{l}.lin_dst.weight"] = sd[f"convs.{l}.lin_src.weight"]
-    x = data.x.detach().cpu().float().clone().requires_grad_(True)
+    x = data.x.detach().cpu().to(dtype).clone().requires_grad_(True)
     ei = data.edge_index.detach().cpu()
     ea = getattr(data, "edge_attr", None)
-    ea = ea.detach().cpu().float() if ea is not None else None
+    ea = ea.detach().cpu().to(dtype) if ea is not None else None
     emb = forward_from_state(sd, (gnn.n_layers, gnn.residual, gnn.edge_dim), x, ei, ea, training=True)
     loss = loss_fn(emb)
     loss.backward()

@@ -1,8 +1,10 @@
 // Host-side validation of the fast binning estimate's acceptance margins (test tool, built by
 // tests/test_binning_margins.py with g++).  For random points it compares the fast estimate,
 // when it claims certainty, with the exact chain of csrc/nsc_math.h.
-//   usage: binning_check N seed emin_deg emax_deg E elev_f64
-//   prints: n az_uncertain el_uncertain az_wrong el_wrong az_slack
+//   usage: binning_check N seed emin_deg emax_deg E elev_f64 [lean [generator]]
+//   prints: n az_uncertain el_uncertain az_wrong el_wrong az_slack s_lo s_hi
+//   lean = 1: check nsc_point_lean (the streaming loop of encode_fast_kernel) instead of nsc_point_pixel; an
+//   "uncertain" point counts in az_uncertain, a certain one must carry the exact pixel.
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -25,11 +27,14 @@ int main(int argc, char **argv)
     double emax = (argc > 4 ? atof(argv[4]) : 2.0) * M_PI / 180.0;
     int E = argc > 5 ? atoi(argv[5]) : 16;
     int f64 = argc > 6 ? atoi(argv[6]) : 1;
+    int lean = argc > 7 ? atoi(argv[7]) : 0;
+    int only_mode = argc > 8 ? atoi(argv[8]) : -1;     // -1: mix of the four generators below
     NscBinParams bp = nsc_make_bin_params(E, emin, emax, 1.0f, 80.0f, f64);
     long azu = 0, elu = 0, azw = 0, elw = 0;
     for (long i = 0; i < n; ++i) {
         float x, y, z;
         int mode = (int)(next() % 4);
+        if (only_mode >= 0) mode = only_mode;
         if (mode == 0) {                       // spherical like the bench clouds
             double az = (u01() * 2 - 1) * M_PI, el = (u01() * 100 - 50) * M_PI / 180, r = 0.5 + u01() * 89.5;
             x = (float)(r * cos(el) * cos(az)); y = (float)(r * cos(el) * sin(az)); z = (float)(r * sin(el));
@@ -56,6 +61,19 @@ int main(int argc, char **argv)
         const float sxy = xs + ys, ss = sxy + zs;
         const bool keep = isfinite(x) && isfinite(y) && isfinite(z) && ss >= bp.s_lo && ss <= bp.s_hi;
         int pix; float sv;
+        if (lean) {
+            if (!nsc_lean_ok(bp)) { printf("lean path not valid for these parameters\n"); return 2; }
+            const int st = nsc_point_lean(x, y, z, bp, pix, sv);   // what encode_fast_kernel runs per point
+            if ((st != 0) != keep) { ++azw; ++elw; continue; }
+            if (!keep) continue;
+            if (sv != ss) ++azw;
+            const int epix = nsc_row_exact(z, sxy, bp) * NSC_A + nsc_col_exact(y, x);
+            if (nsc_point_exact(x, y, z, bp) != epix) ++elw;       // the queue's resolver == the definition
+            if (st == 2) { ++azu; continue; }
+            if (pix % NSC_A != epix % NSC_A) ++azw;
+            if (pix / NSC_A != epix / NSC_A) ++elw;
+            continue;
+        }
         const int fl = nsc_point_pixel(x, y, z, bp, pix, sv);      // what the kernel runs
         if ((fl != 0) != keep) { ++azw; ++elw; continue; }
         if (!keep) continue;

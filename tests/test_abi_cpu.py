@@ -90,3 +90,14 @@ def test_binning_margins_host(tmp_path, bias):
         n, azu, elu, azw, elw = map(int, out[:5])
         assert azw == 0 and elw == 0, out
         assert float(out[5]) < 1e-4          # column-edge slack of the exact float32 chain
+    # the lean estimate of encode_fast_kernel (narrow FOV only): never wrong when it claims certainty, and it does
+    # (a quarter of the mixed generator's points sit on bin edges, another quarter on the axes: all uncertain)
+    for args in (["5000000", "17", "-24.8", "2.0", "16", "1", "1"], ["1000000", "18", "-15", "15", "16", "0", "1"],
+                 ["1000000", "19", "-24.8", "2.0", "16", "0", "1"]):
+        out = subprocess.check_output([exe] + args).decode().split()
+        n, azu, elu, azw, elw = map(int, out[:5])
+        assert azw == 0 and elw == 0, out
+    # on bench-like points (generator 0) all but a few 1e-4 are certain: the uncertain queue stays short
+    out = subprocess.check_output([exe, "4000000", "23", "-24.8", "2.0", "16", "1", "1", "0"]).decode().split()
+    n, azu, elu, azw, elw = map(int, out[:5])
+    assert azw == 0 and elw == 0 and azu < 1e-3 * n, out

@@ -190,12 +190,36 @@ def test_train_steps_reduce_loss_and_match_cpu_adam():
         assert torch.allclose(got[k].detach().cpu(), params[k].detach(), rtol=1e-3, atol=2e-5), k
 
 
+def _scene_clouds(place, n_pts=3000):
+    """Synthetic 16-ring scans whose SCENE (range profile: base, tilt, six azimuthal harmonics with place-seeded
+    amplitudes / frequencies / phases) depends on the place id, plus 5 cm of per-visit noise: revisits of a place
+    look alike, different places differ (the descriptor is rotation-invariant, so phases alone would not do)."""
+    rings, steps = 16, n_pts // 16
+    az = np.tile(np.linspace(-np.pi, np.pi, steps, endpoint=False), rings)
+    ring = np.repeat(np.arange(rings), steps)
+    el = np.deg2rad(-24.0 + 25.0 * (ring + 0.5) / rings)
+    ce, se = np.cos(el), np.sin(el)
+    out = []
+    for i, p in enumerate(place):
+        r = np.random.default_rng(int(p))
+        f, a, ph = r.integers(1, 40, 6), r.uniform(0.5, 8.0, 6), r.uniform(0, 2 * np.pi, 6)
+        rng = r.uniform(12, 40) + r.uniform(0, 25) * ring / rings
+        for k in range(6):
+            rng = rng + a[k] * np.sin(f[k] * az + ph[k] + 0.3 * ring * (k % 2))
+        v = np.random.default_rng(1000003 + i)
+        rng = np.clip(rng + v.normal(0, 0.05, rng.shape), 1.5, 79.0)
+        out.append(np.stack([rng * ce * np.cos(az), rng * ce * np.sin(az), rng * se, v.uniform(0, 1, rng.shape)],
+                            1).astype(np.float32))
+    off = np.zeros(len(out) + 1, np.int64)
+    off[1:] = np.cumsum([len(c) for c in out])
+    return np.concatenate(out), off
+
+
 def _config5_dataset(dev):
     """BASELINE configs[4] shape: 15 synthetic sequences -- 9 "KITTI-like" + 6 "NCLT-like" -- 4 541 keyframes in
     all, every sequence a closed course driven 2-3 times so that revisits (positives) exist; descriptors come from the
-    encoder on synthetic clouds whose scene depends on the PLACE, so revisits look alike."""
+    encoder on the place-dependent synthetic scans above."""
     from neural_spectral_codec_amd.encoding import SpectralEncoder
-    from neural_spectral_codec_amd import synth
     rng = np.random.default_rng(7)
     kitti = [454, 110, 466, 80, 27, 276, 110, 110, 407]          # keyframes per sequence, sums to 2 040
     nclt = [420, 415, 418, 412, 421, 415]                        # 2 501
@@ -217,7 +241,7 @@ def _config5_dataset(dev):
         place += list(100000 * s + np.floor((np.arange(ln) % per_lap) / 3).astype(int))    # 3 keyframes share a scene
     poses = np.concatenate(poses)
     enc = SpectralEncoder(n_elevation=16).to(dev)
-    pts, off = synth.make_clouds_packed(place, 3000, "ring")
+    pts, off = _scene_clouds(place)
     desc = enc.encode_points_batch((torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev)))
     return desc, poses, np.asarray(seq_ids)
 
@@ -226,7 +250,12 @@ def test_config5_full_size_train_step():
     """BASELINE configs[4] at its stated size on one GPU: a 4 541-keyframe chain graph over 15 synthetic KITTI+NCLT
     sequences, triplets from the device miner, ONE 1 024-triplet batch through forward + TripletLoss + backward
     (hidden_dim=256, margin=0.1, dropout 0 for parity): loss, every parameter gradient, the input gradient and one
-    Adam step against torch autograd through the restatement (reference src/gnn/trainer.py:186-221)."""
+    Adam step against torch autograd through the restatement (reference src/gnn/trainer.py:186-221).
+
+    Tolerances: train-mode BatchNorm divides by the batch standard deviation, which amplifies float32 rounding; the
+    restatement is therefore evaluated in float32 (the reference's arithmetic) AND float64, and the kernels have to
+    be as close to the float64 result as 4 x the float32 restatement's own distance from it (floor 2e-3 for
+    gradients -- sums over 4 541 nodes in a different order -- and 1e-4 for the embeddings)."""
     import copy
     from neural_spectral_codec_amd.gnn.triplet_miner import create_triplet_miner
     from neural_spectral_codec_amd.keyframe.graph_manager import build_chain_graph
@@ -252,8 +281,14 @@ def test_config5_full_size_train_step():
             c.bias.normal_(0, 0.1)
     cpu_model = copy.deepcopy(m)
     m = m.to(dev)
-    emb_ref, grads_ref, gx_ref, loss_ref = go.reference_gradients(
-        cpu_model, graph, lambda e: go.triplet_loss_reference(e, tt[:, 0], tt[:, 1], tt[:, 2], 0.1) / 4)
+
+    def loss_fn(e):                                               # trainer.py:207-212 (accumulation_steps = 4)
+        return go.triplet_loss_reference(e, tt[:, 0], tt[:, 1], tt[:, 2], 0.1) / 4
+    emb32, g32, gx32, loss32 = go.reference_gradients(cpu_model, graph, loss_fn)
+    emb64, g64, gx64, loss64 = go.reference_gradients(cpu_model, graph, loss_fn, dtype=torch.float64)
+
+    def dist(a, b):                                               # max-norm distance relative to the exact result
+        return ((a.double() - b).abs().max() / (b.abs().max() + 1e-300)).item()
 
     tr = GNNTrainer(m, device="cuda", learning_rate=5e-4, weight_decay=1e-5, margin=0.1, batch_size=1024,
                     accumulation_steps=4)                          # train_multi_dataset.yaml:127-129, trainer.py:187-188
@@ -263,30 +298,38 @@ def test_config5_full_size_train_step():
     emb = m(graph)                                                # trainer.py:205
     loss = tr.criterion.forward_indexed(emb, trip[:, 0], trip[:, 1], trip[:, 2], scale=1.0 / 4)   # :207-212
     loss.backward()                                               # :213
-    assert loss_ref.item() > 0
-    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 1e-7
-    go.assert_within_bar(emb, emb_ref, what="train-mode forward, 4 541 keyframes")
+    assert loss64.item() > 0
+    assert abs(loss.item() - loss64.item()) <= 1e-4 * abs(loss64.item()) + 1e-7
+    assert dist(emb.detach().cpu(), emb64) <= max(1e-4, 4 * dist(emb32, emb64))
     params = dict(m.gnn.named_parameters())
-    gscale = max(v.abs().max().item() for v in grads_ref.values())
+    gscale = max(v.abs().max().item() for v in g64.values())
+    # Exactly-zero gradients (float32 noise on both sides): a bias in front of a batch-statistics BatchNorm; and,
+    # because the triplet gradient sums to zero over the rows, output_proj.bias and the last BatchNorm's bias.
+    zero = {"input_proj.bias", "output_proj.bias", "batch_norms.2.bias"} | {f"convs.{l}.bias" for l in range(3)}
     for k in _key_map(m.gnn):
-        got = params[k].grad.detach().cpu().reshape(grads_ref[k].shape)
-        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
-            assert got.abs().max().item() < 1e-3 * gscale and grads_ref[k].abs().max().item() < 1e-3 * gscale, k
+        got = params[k].grad.detach().cpu().reshape(g64[k].shape)
+        if k in zero:
+            assert got.abs().max().item() < 1e-3 * gscale and g64[k].abs().max().item() < 1e-6 * gscale, k
             continue
-        assert _rel(got, grads_ref[k]) < 2e-3, k                  # float32 sums over 4 541 nodes, different order
-    assert _rel(graph.x.grad.cpu(), gx_ref) < 2e-3
+        assert dist(got, g64[k]) <= max(2e-3, 4 * dist(g32[k], g64[k])), (k, dist(got, g64[k]), dist(g32[k], g64[k]))
+    assert dist(graph.x.grad.cpu(), gx64) <= max(2e-3, 4 * dist(gx32, gx64))
     # one Adam step (lr 5e-4, L2 weight decay 1e-5, trainer.py:115-119) on both sides
+    before = {k: v.detach().cpu().clone() for k, v in params.items()}
     tr.optimizer.step()
     cparams = dict(cpu_model.gnn.named_parameters())
     opt = torch.optim.Adam(cpu_model.parameters(), lr=5e-4, weight_decay=1e-5)
-    for k, gr in grads_ref.items():
+    for k, gr in g32.items():
         cparams[k].grad = gr.reshape(cparams[k].shape)
     opt.step()
     for k in _key_map(m.gnn):
-        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
+        if k in zero:
             continue          # zero-gradient parameters: Adam turns rounding noise into +-lr steps on either side
-        assert torch.allclose(params[k].detach().cpu().reshape(cparams[k].shape), cparams[k].detach(),
-                              rtol=1e-3, atol=2e-5), k
+        new, ref = params[k].detach().cpu().reshape(cparams[k].shape), cparams[k].detach()
+        assert not torch.equal(new, before[k].reshape(new.shape)), k
+        # the first Adam step moves every element by lr * sign(g) (|g| >> eps): compare the step, not the weight
+        step_gpu, step_ref = new - before[k].reshape(new.shape), ref - before[k].reshape(new.shape)
+        big = g64[k].abs() > 1e-3 * g64[k].abs().max()            # elements whose gradient sign is well determined
+        assert torch.allclose(step_gpu[big], step_ref[big], rtol=2e-2, atol=1e-6), k
 
 
 def test_dropout_masks():

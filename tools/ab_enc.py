@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neural_spectral_codec_amd import synth
 from neural_spectral_codec_amd.encoding import SpectralEncoder
-n, npts = 1024, 120000
+n, npts = int(os.environ.get("AB_CLOUDS", "1024")), 120000
 enc = SpectralEncoder(n_elevation=16).to("cuda")
-pts, off = synth.make_clouds_device(n, npts, "cuda")
+pts, off = synth.make_clouds_device(n, npts, "cuda", order=os.environ.get("AB_ORDER", "uniform"))
 out = torch.empty((n, 800), device="cuda")
 cfgs = sys.argv[1:] or ["VARIANT=0"]
 def setenv(c):

@@ -46,6 +46,8 @@ def build_hip(force=False, verbose=False):
     flags = list(HIPCC_FLAGS)
     if os.environ.get("NSC_DEV_BUILD") == "1":       # enables the NSC_TUNE_* development knobs
         flags.append("-DNSC_DEV_TUNING")
+    for d in os.environ.get("NSC_DEV_DEFINES", "").split():      # development A/B builds
+        flags.append("-D" + d)
     cmd = [hipcc] + flags + ["-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd))

@@ -19,6 +19,8 @@
 //                        the NSC_GAT_CORESIDENT set: no LDS, < 64 VGPRs, bit-identical output -- fits beside a
 //                        resident encoder grid so that the GNN of batch k runs under the encoder of batch k+1
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/nsc.h"
 
@@ -151,6 +153,20 @@ __global__ __launch_bounds__(256) void gat_fold_kernel(PrepArgs a, float *__rest
     }
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, dispatch), each with
+// its own L2: with the natural order the 4 (or 13) column blocks that share an A row block -- and neighbouring
+// target nodes that share their neighbour rows -- land on different XCDs and every one of them fetches the rows
+// again from beyond L2.  Renumbering (bijective for any grid size) gives the workgroups of ONE XCD consecutive
+// tiles.  Speed only: the result does not depend on placement.
+__device__ __forceinline__ unsigned xcd_tile(unsigned id, unsigned n)
+{
+#ifdef NSC_DEV_NOREMAP
+    return id;
+#endif
+    const unsigned xcd = id & 7u, q = n >> 3, r = n & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (id >> 3);
+}
+
 // ---------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * B[N,K]^T, f32 MFMA 16x16x4.  Workgroup 256 threads = 4 waves, tile 32 x 64:
 // wave w owns columns [16w, 16w+16) x 32 rows (two accumulators share the B operand).
@@ -169,11 +185,15 @@ struct GemmEpi {
 
 // EPI: 0 = plain store + aux columns (lin), 1 = bias + BatchNorm + ReLU (input_proj),
 //      2 = bias + residual (output_proj / residual_proj)
-// Tiles of A (16*ACC x 64) and B (64 x 64) are staged through LDS: global loads are 256-byte row
-// segments (16 lanes x 16 B), each element is fetched once per workgroup, and the MFMA operands are
-// ds_read_b128 from rows padded to 68 floats.  Two LDS stages: the next chunk's global loads are in
-// flight while the current chunk's MFMAs run.
-template <int ACC, int EPI>   // ACC accumulators of 16 rows each per wave: workgroup tile (16*ACC) x 64
+//
+// Tiles of A (16*ACC x 64) and B (64 x 64) are staged through LDS: global loads are 256-byte row segments
+// (16 lanes x 16 B), each element is fetched once per workgroup, rows are padded to 68 floats; the MFMA operands are
+// ds_read_b128.  Two LDS stages fed from a register ring of prefetched chunks (the operand fetch -- L2 / Infinity
+// Cache round trips, the A rows were written by the previous kernel on other XCDs -- is what bounds these GEMMs).
+// The epilogue goes back through LDS so that every output row leaves as 256 contiguous bytes (float4 per lane);
+// the residual is read the same way.  (Measured and dropped in round 2: two MFMA chains per tile, operand fetches
+// one block ahead of the MFMAs, a two-slot ring -- 20 % slower on the 13-chunk input projection.)
+template <int ACC, int EPI>   // ACC accumulator row blocks of 16 rows per wave: workgroup tile (16*ACC) x 64
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ A, int lda,
                                                       const float *__restrict__ B, int ldb,
                                                       const float *__restrict__ Bx, int M, int N,
@@ -188,8 +208,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int cb = n0 + wave * 16 + r;
+    const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int m0 = (int)(tile / gridDim.x) * BM, n0 = (int)(tile % gridDim.x) * BN;
 
     // staging map: float4 f = tid + 256 i -> tile row f / 16, k offset 4 (f % 16).  Rows / columns
     // past the matrix re-read a valid row: their products only reach outputs that are never stored.
@@ -212,17 +232,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
         gb[i] = ((gc < n_main) ? B + (long long)gc * ldb : Bx + (long long)(gc - n_main) * ldb) + 4 * c4;
         sb[i] = row * LD + 4 * c4;
     }
-
-    // epilogue operands of this lane's column, fetched up front (off the critical path)
-    const int col = cb < N ? cb : N - 1;
-    float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
-    if (EPI != 0) bias = ep.bias[col];
-    if (EPI == 1) {
-        // torch batch_norm eval: alpha = invstd * weight, beta = bias - mean * alpha
-        const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
-        bn_scale = invstd * ep.bn_w[col];
-        bn_shift = ep.bn_b[col] - ep.bn_mean[col] * bn_scale;
-    }
+    const int c4t = tid & 15;                  // every float4 of this thread sits at k offset 4 * c4t of a chunk
 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[ACC];
@@ -294,24 +304,58 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
         }
     }
 
-    // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
-    if (cb >= N) return;
-    const bool main_col = cb < n_main;
+    // epilogue: the tile goes through LDS (stage buffers are free after the last barrier), rows leave as float4
+    float *Cs = Bs[0];                                         // BM x LD floats fit (BM <= 64)
 #pragma unroll
-    for (int h = 0; h < ACC; ++h) {
+    for (int h = 0; h < ACC; ++h)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = m0 + 16 * h + 4 * q + reg;
-            if (row >= M) continue;
-            float v = acc[h][reg];
-            if (main_col) {
-                if (EPI != 0) v = v + bias;
-                if (EPI == 1) v = fmaxf(v * bn_scale + bn_shift, 0.0f);
-                if (EPI == 2 && ep.resid) v = v + ep.resid[(long long)row * ep.ldr + cb];
-                C[(long long)row * ldc + cb] = v;
-            } else {
-                float *aux = (cb == n_main) ? ep.aux0 : ep.aux1;
-                aux[row] = v;
+        for (int reg = 0; reg < 4; ++reg)                     // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+            Cs[(16 * h + 4 * q + reg) * LD + wave * 16 + r] = acc[h][reg];
+    __syncthreads();
+    const int cg = n0 + 4 * c4t;                               // first of this thread's 4 columns
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, bn_scale[4] = {1.f, 1.f, 1.f, 1.f}, bn_shift[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = (cg + j < N) ? cg + j : N - 1;
+        if (EPI != 0) bias[j] = ep.bias[col];
+        if (EPI == 1) {
+            // torch batch_norm eval: alpha = invstd * weight, beta = bias - mean * alpha
+            const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
+            bn_scale[j] = invstd * ep.bn_w[col];
+            bn_shift[j] = ep.bn_b[col] - ep.bn_mean[col] * bn_scale[j];
+        }
+    }
+    const bool vec = (cg + 3 < n_main) && !(ldc & 3) && !(reinterpret_cast<unsigned long long>(C) & 15) &&
+                     (EPI != 2 || !ep.resid || (!(ep.ldr & 3) && !(reinterpret_cast<unsigned long long>(ep.resid) & 15)));
+#pragma unroll
+    for (int pass = 0; pass < BM / 16; ++pass) {
+        const int lr = pass * 16 + (tid >> 4), row = m0 + lr;
+        if (row >= M) continue;
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(&Cs[lr * LD + 4 * c4t]);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        f32x4 rs = zero;
+        if (EPI == 2 && ep.resid && vec) rs = *reinterpret_cast<const f32x4 *>(ep.resid + (long long)row * ep.ldr + cg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (EPI != 0) v[j] = v[j] + bias[j];
+            if (EPI == 1) v[j] = fmaxf(v[j] * bn_scale[j] + bn_shift[j], 0.0f);
+        }
+        if (vec) {
+            if (EPI == 2 && ep.resid) { v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w; }
+            *reinterpret_cast<f32x4 *>(C + (long long)row * ldc + cg) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cg + j;
+                if (col >= N) continue;
+                if (col < n_main) {
+                    float o = v[j];
+                    if (EPI == 2 && ep.resid) o = o + ep.resid[(long long)row * ep.ldr + col];
+                    C[(long long)row * ldc + col] = o;
+                } else {
+                    float *aux = (col == n_main) ? ep.aux0 : ep.aux1;
+                    aux[row] = v[j];
+                }
             }
         }
     }
@@ -335,7 +379,8 @@ __global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__rest
     constexpr int BM = 16 * ACC, P = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 64;
+    const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int m0 = (int)(tile / gridDim.x) * BM, n0 = (int)(tile % gridDim.x) * 64;
     const int cb = n0 + wave * 16 + r;
 
     // Load mapping: lane L fetches 16 bytes of row L >> 2 at k offset 4 (L & 3), so 4 neighbouring lanes read
@@ -465,7 +510,7 @@ template <int CH, int UR, bool PRE>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = (int)xcd_tile(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);   // an XCD takes a contiguous node range
     if (i >= a.N) return;
     const int beg = a.row_ptr[i], end = a.row_ptr[i + 1];
     const float ad = a.a_dst[i];
@@ -653,26 +698,42 @@ int check_model(const NscGatModel *m)
     return NSC_OK;
 }
 
+#ifdef NSC_DEV_TUNING
+int gat_tune_env(const char *name, int def)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : def;
+}
+#endif
+
 template <int EPI>
 void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const float *B, int ldb, const float *Bx,
                  int M, int N, int n_main, int K, float *C, int ldc, const GemmEpi &ep)
 {
-    // two 16-row accumulators per wave share the B operand; with few row tiles use one so that
-    // every SIMD of the chip gets a wave (the GEMMs here are latency-, not throughput-bound)
-    const long long wgs2 = (long long)((N + 63) / 64) * ((M + 31) / 32);
-    const bool two = wgs2 >= 384 && !coresident;
+    // Tile choice (measured at M = 1 024 and 4 541, round 2): 32-row tiles (two accumulators share the B operand, 1.7x
+    // less operand traffic per MFMA) as soon as they still give >= 1.5 workgroups per CU; below that 16-row tiles, so
+    // that every SIMD of the chip gets a wave -- these GEMMs are operand-latency-, not MFMA-bound.
+    const long long w2 = (long long)((N + 63) / 64) * ((M + 31) / 32);
+    bool two = w2 >= 384 && !coresident;
+    unsigned pad = 0;
+#ifdef NSC_DEV_TUNING
+    const int force = gat_tune_env("NSC_TUNE_GEMM_ACC", 0);
+    if (force == 1) two = false;
+    if (force == 2) two = !coresident;
+    pad = (unsigned)gat_tune_env("NSC_TUNE_GEMM_LDSPAD", 0);
+#endif
     const dim3 grid((N + 63) / 64, two ? (M + 31) / 32 : (M + 15) / 16);
     if (coresident) {
-        // one accumulator: 48 VGPRs.  Larger tiles (2 or 4 accumulators, fewer B re-reads) were measured to
-        // disturb the co-running encoder MORE (longer uninterrupted MFMA bursts), DESIGN.md section 7.
+        // one accumulator row block: 48 VGPRs.  Larger tiles (fewer B re-reads) were measured to disturb the
+        // co-running encoder MORE (longer uninterrupted MFMA bursts), DESIGN.md section 7.
         hipLaunchKernelGGL((gemm_nt_direct_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N,
                            n_main, K, C, ldc, ep);
     } else {
         if (two)
-            hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main,
+            hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), pad, st, A, lda, B, ldb, Bx, M, N, n_main,
                                K, C, ldc, ep);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main,
+            hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), pad, st, A, lda, B, ldb, Bx, M, N, n_main,
                                K, C, ldc, ep);
     }
 }

@@ -26,6 +26,13 @@ def _dev_f32(t, device=None):
     return t.contiguous()
 
 
+def _pos_f32(p, device):
+    """(n,3) positions (host array or tensor on any device) -> contiguous float32 tensor on `device`."""
+    if not isinstance(p, torch.Tensor):
+        p = torch.from_numpy(np.asarray(p, dtype=np.float32))
+    return p.detach().to(device=device, dtype=torch.float32).reshape(-1, 3).contiguous()
+
+
 def _cdf(h: torch.Tensor, eps: float, divide_plain: bool) -> torch.Tensor:
     out = torch.empty_like(h)
     with torch.cuda.device(h.device):
@@ -172,7 +179,7 @@ class WassersteinRetriever:
             # the database form of the normalisation (wasserstein.py:158-163), done once per inserted row
             self._cdf_buf[self.database_size:need] = _cdf(h, 1e-8, False)
         if positions is not None:
-            self._pos[self.database_size:need] = torch.as_tensor(np.asarray(positions), dtype=torch.float32).to(self.device)
+            self._pos[self.database_size:need] = _pos_f32(positions, self.device)
         self.database_size = need
 
     def query_batch(self, query_hists, top_k: int = 10, query_positions=None, min_distance: float = 0.0):
@@ -188,7 +195,7 @@ class WassersteinRetriever:
         db = self._buf[:self.database_size]
         qp = dbp = None
         if query_positions is not None:
-            qp = torch.as_tensor(np.asarray(query_positions), dtype=torch.float32).to(self.device).reshape(-1, 3).contiguous()
+            qp = _pos_f32(query_positions, self.device)
             dbp = self._pos[:self.database_size]
         if self._cdf_buf is not None:
             dist = _distances_cdf(self._cdf_buf[:self.database_size], _cdf(q, 1e-8, True), dbp, qp, min_distance)

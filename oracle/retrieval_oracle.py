@@ -48,3 +48,19 @@ def topk(dist, k):
     """WassersteinRetriever.query, wasserstein.py:360-366: k smallest, ascending (ties: lower index)."""
     order = np.lexsort((np.arange(len(dist)), dist))[:k]
     return order, dist[order]
+
+
+def stage1(desc, poses, has_pose, query, top_k=10, min_dist=50.0, eps=1e-8):
+    """Stage 1 of TwoStageRetrieval for one query keyframe of the database itself
+    (two_stage_retrieval.py:145-202): rows closer than min_dist to the query (both poses known, translation
+    distance, :160-170) are skipped, the rest ranked by W1 (wasserstein.py:134-172), top_k returned.
+    PINNED by tests/golden/two_stage.npz (oracle/gen_golden_two_stage.py)."""
+    desc = np.asarray(desc, np.float32)
+    pos = np.asarray(poses, np.float64)[:, :3, 3]
+    d = batch(desc[query], desc, eps).astype(np.float64)
+    if has_pose[query]:
+        near = np.linalg.norm(pos - pos[query], axis=1) < min_dist
+        d = np.where(near & np.asarray(has_pose, bool), np.inf, d)
+    order = np.lexsort((np.arange(len(d)), d))
+    order = order[np.isfinite(d[order])][:top_k]
+    return order, d[order]

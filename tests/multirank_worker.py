@@ -68,7 +68,17 @@ def main():
         path.synchronize()
         torch.cuda.synchronize(dev)
     desc_all, emb = res
+    # the consumer of the gathered matrix: stage-1 retrieval with the database rows sharded over the ranks
+    # (two_stage_retrieval.py:145-202) -- every rank scores its own rows, ONE all-gather of k candidates, merge
+    from neural_spectral_codec_amd.retrieval import ShardedTwoStageRetrieval, WassersteinRetriever
+    sh = ShardedTwoStageRetrieval(WassersteinRetriever(device=dev), a.n_total, top_k=10, spatial_filter_distance=8.0)
+    pos = torch.from_numpy(poses[:, :3, 3].astype(np.float32)).to(dev)
+    sh.add_local_rows(desc_all[lo:hi], pos[lo:hi])
+    qsel = torch.tensor([0, a.n_total // 3, a.n_total // 2, a.n_total - 1], device=dev)
+    r_idx, r_val = sh.query_batch(desc_all[qsel], pos[qsel])
+    torch.cuda.synchronize(dev)
     out = {"lo": lo, "hi": hi, "desc_all": desc_all.cpu().numpy(), "emb": emb.cpu().numpy(),
+           "retr_idx": r_idx.cpu().numpy(), "retr_val": r_val.cpu().numpy(),
            "coresident": int(bool(getattr(getattr(model, "gnn", model), "coresident", False)))}
     if pipelined:
         out["desc_all_kept"] = kept[0].cpu().numpy()

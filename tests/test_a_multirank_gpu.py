@@ -84,5 +84,9 @@ def test_sharded_path_through_hip_kernels_matches_single_process(tmp_path, singl
         if mode == "pipelined":      # a result two steps old is still intact (4 buffers in rotation)
             assert np.array_equal(z["desc_all_kept"].view(np.uint32), ref["desc_all"].view(np.uint32))
             assert np.array_equal(z["emb_kept"].view(np.uint32), ref["emb"][lo:hi].view(np.uint32))
+        # row-sharded stage-1 retrieval == retrieval over the whole database on one GPU, ties included
+        assert np.array_equal(z["retr_idx"], ref["retr_idx"]), f"rank {r} retrieval indices"
+        assert np.array_equal(z["retr_val"].view(np.uint32), ref["retr_val"].view(np.uint32)), f"rank {r} distances"
         covered += hi - lo
     assert covered == n_total
+    assert (ref["retr_idx"][:, 0] >= 0).all() and np.isfinite(ref["retr_val"][:, 0]).all()

@@ -163,3 +163,82 @@ def test_gradient_all_reduce_and_triplet_split():
         wsum += wgt
     assert np.array_equal(np.concatenate(rows), np.arange(30).reshape(10, 3))
     assert abs(wsum - 1.0) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# stage-1 retrieval over database rows sharded across the ranks (BASELINE configs[3])
+# ---------------------------------------------------------------------------------------------
+class OracleLocalRetriever:
+    """query_batch() of WassersteinRetriever over this rank's rows, computed by the numpy oracle."""
+
+    def __init__(self):
+        self.rows, self.pos = None, None
+
+    def add_to_database(self, histograms, positions=None):
+        self.rows = np.asarray(histograms, np.float32)
+        self.pos = None if positions is None else np.asarray(positions, np.float32)
+
+    def query_batch(self, query_hists, top_k=10, query_positions=None, min_distance=0.0):
+        import retrieval_oracle as ro
+        q = np.asarray(query_hists, np.float32)
+        idx = np.zeros((len(q), top_k), np.int64)
+        val = np.zeros((len(q), top_k), np.float32)
+        for i in range(len(q)):
+            d = ro.batch(q[i], self.rows).astype(np.float32)
+            if query_positions is not None and self.pos is not None:
+                near = np.linalg.norm(self.pos - np.asarray(query_positions, np.float32)[i], axis=1) < min_distance
+                d = np.where(near, np.float32(np.inf), d)
+            order = np.lexsort((np.arange(len(d)), d))[:top_k]
+            idx[i], val[i] = order, d[order]
+        return torch.from_numpy(idx), torch.from_numpy(val)
+
+
+def _retrieval_case(n_total):
+    rng = np.random.default_rng(11)
+    base = (rng.random((40, 800)) ** 4).astype(np.float32)
+    desc = base[np.arange(n_total) % 40] * (1 + 0.05 * rng.random((n_total, 800)).astype(np.float32))
+    desc = (desc / desc.sum(1, keepdims=True)).astype(np.float32)
+    desc[7] = desc[3]                                   # exact duplicates: ties must resolve to the smaller index
+    desc[n_total - 2] = desc[3]
+    pos = (rng.random((n_total, 3)) * 200).astype(np.float32)
+    queries = [3, n_total // 2, n_total - 1]
+    return desc, pos, queries
+
+
+def _retrieval_worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neural_spectral_codec_amd.retrieval import ShardedTwoStageRetrieval
+        desc, pos, queries = _retrieval_case(n_total)
+        sh = ShardedTwoStageRetrieval(OracleLocalRetriever(), n_total, top_k=10, spatial_filter_distance=50.0)
+        sh.add_local_rows(desc[sh.lo:sh.hi], pos[sh.lo:sh.hi])
+        idx, val = sh.query_batch(desc[queries], pos[queries])
+        q.put((rank, sh.lo, sh.hi, idx.numpy(), val.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,world", [(64, 2), (37, 3), (9, 2)])
+def test_row_sharded_retrieval_matches_single_process(n_total, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_retrieval_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    desc, pos, queries = _retrieval_case(n_total)
+    single = OracleLocalRetriever()
+    single.add_to_database(desc, pos)
+    k = min(10, n_total)
+    want_idx, want_val = single.query_batch(desc[queries], k, pos[queries], 50.0)
+    want_idx = torch.where(torch.isinf(want_val), torch.full_like(want_idx, -1), want_idx).numpy()
+    for rank, lo, hi, idx, val in res:
+        assert (lo, hi) == nd.shard_range(n_total, rank, world)
+        assert np.array_equal(idx, want_idx), (rank, idx, want_idx)          # identical on every rank, ties included
+        assert np.array_equal(val, want_val.numpy())

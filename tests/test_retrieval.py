@@ -119,3 +119,82 @@ def test_gpu_cached_cdf_kernels(n, nq, dim):
             # same set up to near-ties at the float32 summation-order level
             close = np.abs(d[idx[j][fin]] - dv[fin]) <= RTOL * np.abs(dv[fin]) + 1e-5
             assert close.all(), (j, filt)
+
+
+# ---------------------------------------------------------------------------------------------
+# stage 1 of TwoStageRetrieval (two_stage_retrieval.py:91-202) and its row-sharded form
+# ---------------------------------------------------------------------------------------------
+T = np.load(os.path.join(os.path.dirname(__file__), "golden", "two_stage.npz"))
+# W1 = sum over 800 bins of |CDF difference|, CDFs are float32 cumulative sums in [0, 1] computed in different orders
+# on each side: absolute agreement ~800 x 1e-7; the revisit distances here are ~0.2, so the bound is absolute
+ATOL1 = 2e-4
+
+
+def _keyframes():
+    from types import SimpleNamespace
+    return [SimpleNamespace(keyframe_id=1000 + i, scan_id=i, points=np.zeros((4, 3), np.float32),
+                            pose=(T["poses"][i] if T["has_pose"][i] else None), timestamp=float(i),
+                            descriptor=T["desc"][i], embedding=None) for i in range(len(T["desc"]))]
+
+
+def test_stage1_oracle_matches_reference():
+    k, thr = int(T["top_k"]), float(T["thr"])
+    for qi, q in enumerate(T["queries"]):
+        idx, dist = ro.stage1(T["desc"], T["poses"], T["has_pose"], int(q), k, thr)
+        want = T["idx"][qi]
+        assert idx.tolist() == want[want >= 0].tolist()
+        assert np.allclose(dist, T["dist"][qi][want >= 0], rtol=RTOL, atol=ATOL1)
+
+
+@pytest.mark.gpu
+def test_two_stage_retrieval_stage1_matches_reference():
+    from neural_spectral_codec_amd import _lib
+    from neural_spectral_codec_amd.retrieval import (LoopClosureCandidate, TwoStageRetrieval, batch_loop_closing,
+                                                     create_two_stage_retrieval)
+    kfs = _keyframes()
+    k, thr = int(T["top_k"]), float(T["thr"])
+    r = create_two_stage_retrieval(top_k=k, spatial_filter_distance=thr)
+    for kf in kfs[:150]:
+        r.add_keyframe(kf)                                  # one CDF row appended per call (:91-105)
+    r.add_keyframes(kfs[150:])
+    assert r.retriever.database_size == len(kfs) == len(r.keyframes)
+    for qi, q in enumerate(T["queries"]):
+        cands = r._global_retrieval(kfs[int(q)])
+        assert all(isinstance(c, LoopClosureCandidate) and not c.verified for c in cands)
+        want = T["idx"][qi]
+        assert [c.database_idx for c in cands] == want[want >= 0].tolist()
+        assert np.allclose([c.distance for c in cands], T["dist"][qi][want >= 0], rtol=RTOL, atol=ATOL1)
+        assert [c.database_idx for c in r.query(kfs[int(q)], verify=False)] == [c.database_idx for c in cands]
+    batch = r.global_retrieval_batch([kfs[int(q)] for q in T["queries"]])
+    assert [[c.database_idx for c in b] for b in batch] == [row[row >= 0].tolist() for row in T["idx"]]
+    with pytest.raises(ValueError):
+        r.add_keyframe(type("K", (), {"descriptor": None, "pose": None})())
+    # stage 2 is injected (Open3D GICP is outside the descriptor path)
+    with pytest.raises(_lib.NscError):
+        r.query(kfs[3])
+    with pytest.raises(_lib.NscError):
+        r.get_loop_closures(kfs[3])
+
+    class FakeVerifier:
+        def verify(self, qp, cp):
+            return True, np.eye(4), {"fitness": 0.9, "rmse": 0.1, "information_matrix": np.eye(6)}
+
+    def edge(source_pose, target_pose, relative_transform, information_matrix):
+        return {"relative_transform": relative_transform}
+    r2 = TwoStageRetrieval(top_k=k, spatial_filter_distance=thr, verifier=FakeVerifier(), edge_fn=edge)
+    r2.add_keyframes(kfs)
+    lcs = r2.get_loop_closures(kfs[int(T["queries"][0])])
+    assert len(lcs) == k and lcs[0]["source_id"] == 1000 + int(T["queries"][0])
+    assert [e["target_id"] - 1000 for e in lcs] == T["idx"][0].tolist() and lcs[0]["fitness"] == 0.9
+    res = batch_loop_closing([kfs[int(q)] for q in T["queries"][:2]], kfs, top_k=k, spatial_filter_distance=thr, verify=False)
+    assert [c.database_idx for c in res[1]] == T["idx"][1].tolist()
+    r.clear_database()
+    assert r._global_retrieval(kfs[0]) == [] and r.retriever.database_size == 0
+
+
+def test_merge_topk_ties_and_padding():
+    from neural_spectral_codec_amd.retrieval.two_stage_retrieval import merge_topk
+    d = torch.tensor([[0.5, 0.7, float("inf"), 0.5, 0.6, 0.9]])       # two ranks x 3 candidates, a tie at 0.5
+    i = torch.tensor([[4, 9, -1, 12, 20, 31]])
+    idx, val = merge_topk(d, i, 4)
+    assert idx.tolist() == [[4, 12, 20, 9]] and val.tolist() == [[0.5, 0.5, pytest.approx(0.6), pytest.approx(0.7)]]

@@ -115,6 +115,62 @@ def cpu_baseline(pts_dev, off_dev, model, n_sample):
 
 EV_EVERY = 4
 CALIB_STEPS = 30
+GAT_FLOP_PER_NODE = 2.0 * (800 * 256 + 3 * 256 * 256 + 256 * 800)      # 5.51 GFLOP at N = 4 541
+MFMA_F32_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md: f32-input MFMA
+
+
+def measure_extras(enc, model, dev, n_local, scratch):
+    """Untimed side measurements reported next to the headline (rank 0, N = 1, after the timed region):
+      * the GAT half alone on BASELINE configs[2] (4 541 keyframes, 18 158 edges): HIP-event time per forward and
+        the f32-MFMA rate it amounts to (the rocprofv3 counter figures of the same workload are under profiles/);
+      * the encoder kernel alone on SENSOR-ORDERED clouds (azimuth-major = HDL-64 firing order, ring-major): the
+        LDS-atomic contention case of SURVEY section 7, next to the uniform-order launch."""
+    from neural_spectral_codec_amd import synth
+    from neural_spectral_codec_amd.keyframe import graph_manager as gm
+    out = {}
+    with torch.no_grad():
+        inner = getattr(model, "gnn", model)
+        was = inner.coresident
+        inner.coresident = False
+        gat = {}
+        for n in (4541, n_local):
+            g = gm.synthetic_chain_graph(n, device=dev, seed=1)
+            for _ in range(5):
+                model(g)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(50):
+                model(g)
+            b.record()
+            torch.cuda.synchronize(dev)
+            us = a.elapsed_time(b) / 50 * 1e3
+            gat[n] = us
+        inner.coresident = was
+        tf = GAT_FLOP_PER_NODE * 4541 / (gat[4541] * 1e-6) / 1e12
+        out["roofline_gat"] = {
+            "bound": "mfma_f32", "kernel": "gemm_nt_kernel (800->256, 3 x 256->256, 256->800) + gat_aggregate_kernel",
+            "workload": "BASELINE.json configs[2]: 4541 keyframes, 18158 temporal edges, edge_dim=2, eval mode, one GPU",
+            "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+            "flop_per_forward": GAT_FLOP_PER_NODE * 4541, "forward_us": gat[4541],
+            "forward_us_at_step_size": gat[n_local], "traffic": None,
+            "note": "whole forward (8 launches) by HIP events; per-kernel durations and the MFMA counters "
+                    "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32) are in profiles/r02_gat_n4541_*",
+        }
+        orders = {}
+        for order in ("azimuth_major", "ring_major"):
+            pts, off = synth.make_clouds_device(n_local, N_POINTS, dev, seed=77, order=order)
+            for _ in range(3):
+                enc.encode_points_batch((pts, off), out=scratch)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                enc.encode_points_batch((pts, off), out=scratch)
+            b.record()
+            torch.cuda.synchronize(dev)
+            orders[order] = a.elapsed_time(b) / 20
+            del pts, off
+        out["encoder_input_order_ms"] = orders
+    return out
 
 
 def main():
@@ -125,6 +181,8 @@ def main():
     ap.add_argument("--clouds", type=int, default=N_CLOUDS, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample", type=int, default=1024, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)   # skip the untimed side measurements
+    ap.add_argument("--gnn-kernels", choices=["auto", "lds", "direct"], default="auto", help=argparse.SUPPRESS)
     ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)      # force the one-stream path
     ap.add_argument("--pipelined", action="store_true", help=argparse.SUPPRESS)   # force the two-stream path
     args = ap.parse_args()
@@ -189,6 +247,7 @@ def main():
 
     inner_gnn = getattr(model, "gnn", model)
     paths = {"pipelined": make_path(True), "serial": make_path(False)}
+    paths["pipelined"].coresident_gnn = args.gnn_kernels != "lds"
     path = paths["serial" if args.serial else "pipelined"]
 
     def sync():
@@ -201,7 +260,8 @@ def main():
     def use(name):
         nonlocal path
         path = paths[name]
-        inner_gnn.coresident = (name == "pipelined")        # LDS-free GNN kernels only where they co-run
+        # LDS-free GNN kernels only where they co-run with a resident encoder grid
+        inner_gnn.coresident = (name == "pipelined") if args.gnn_kernels == "auto" else (args.gnn_kernels == "direct")
 
     SPINUP_STEPS = 40    # untimed device spin-up (clock ramp, TLB/first touch): ~16 ms, part of setup
     calib = None
@@ -262,6 +322,9 @@ def main():
             b.record()
         torch.cuda.synchronize(dev)
         solo_ms = float(np.mean([a.elapsed_time(b) for a, b in solo]))
+        extras = {}
+        if rank == 0 and world == 1 and not args.no_extras:
+            extras = measure_extras(enc, model, dev, n_local, scratch)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,7 +350,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
             "config": {
-                "workload": f"{n_local} clouds x {N_POINTS} points per GPU (BASELINE.json configs[1]) "
+                "workload": f"{n_local} clouds x {N_POINTS} points per GPU, i.i.d. uniform points in random order "
+                            f"(BASELINE.json configs[1]; sensor-ordered clouds: roofline.standalone_launch_ms_by_input_order) "
                             f"+ 3-layer GAT forward over the {n_local}-keyframe temporal chain "
                             f"(5 temporal neighbours, edge_dim=2, eval mode)"
                             + (f", RCCL all-gather of {world} x ({n_local},800) f32 descriptor shards"
@@ -296,7 +360,7 @@ def main():
                 "gat": "800->256->GATx3->800", "parallelism": f"keyframe-shard x{world}",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "encode_fused_kernel", "achieved": achieved,
+                "bound": "hbm", "kernel": "encode_fast_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "launch_ms": enc_ms, "launches_timed": len(ev[::EV_EVERY]),
                 "co_running": None if chosen == "serial" else "GNN forward of the previous batch on a second stream",
@@ -305,6 +369,11 @@ def main():
                 "algorithmic_bytes_per_launch": n_local * BYTES_PER_CLOUD,
             },
         }
+        if extras:
+            line["roofline_gat"] = extras["roofline_gat"]
+            # the headline workload is the uniform-order batch; the same kernel alone on sensor-ordered clouds:
+            line["roofline"]["standalone_launch_ms_by_input_order"] = dict(
+                uniform=solo_ms, **extras["encoder_input_order_ms"])
         if world == 1 and not args.no_cpu_baseline:
             cb, odesc = cpu_baseline(pts, off, model, min(args.cpu_sample, n_local))
             line["cpu_baseline"] = cb

@@ -106,6 +106,7 @@ class ShardedDescriptorPath:
                  n_layers: int = 3, group=None, overlap: bool = True, pipeline: bool = False):
         self.encoder, self.gnn, self.group = encoder, gnn, group
         self.pipeline = pipeline
+        self.coresident_gnn = True         # pipeline mode: launch the GNN in its NSC_GAT_CORESIDENT form
         self._k = 0
         self._streams = None
         self.last_event = None
@@ -144,7 +145,7 @@ class ShardedDescriptorPath:
 
     def _pipe_setup(self, device):
         inner = getattr(self.gnn, "gnn", self.gnn)
-        if hasattr(inner, "coresident"):
+        if hasattr(inner, "coresident") and self.coresident_gnn:
             inner.coresident = True
         n_local, d = self.hi - self.lo, int(getattr(self.encoder, "output_dim", 800))
         nb = self._PIPE_BUFFERS

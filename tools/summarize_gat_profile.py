@@ -75,6 +75,6 @@ for k in ("1>", "0>", "2>"):
           f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / n_mfma:.1f} | {gui:.0f} | {util * 100:.1f} % | {wi * 100:.0f} % | {wa * 100:.0f} % |")
 print("\n`SQ_INSTS_VALU_MFMA_MOPS_F32 x 512` reproduces the algorithmic FLOP count (padding rows of the last tile included); "
       "`SQ_VALU_MFMA_BUSY_CYCLES` is 32 cycles per `v_mfma_f32_16x16x4_f32`. `MfmaUtil` is rocprofv3's own derived formula "
-      "(busy cycles over elapsed cycles x SIMDs, elapsed = GRBM_GUI_ACTIVE per XCD); the guide notes that this quotient reads high on "
-      "dispatches shorter than 0.3 ms, so the time-based column of the first table (FLOP / duration against the 157.3 TF peak at "
-      "2.4 GHz) is the conservative figure.")
+      "(busy cycles over elapsed cycles x SIMDs, elapsed = GRBM_GUI_ACTIVE per XCD); MI355X_MICROARCH.md notes that GRBM_GUI_ACTIVE reads high "
+      "on dispatches shorter than 0.3 ms, so this column is a lower bound; the time-based column of the first table is FLOP / duration "
+      "against the 157.3 TF peak (2.4 GHz).")

@@ -14,12 +14,12 @@ for r in stats[:22]:
 rows = list(csv.DictReader(open(glob.glob(d + "/*/*kernel_trace.csv")[0])))
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 SOLO = 20   # bench.py ends with 20 encoder-only reference launches outside the timed region
-enc = [k for k in ks if 'encode_fused' in k[2]][-(SOLO + 60):-SOLO]
+enc = [k for k in ks if ('encode_fused' in k[2] or 'encode_fast' in k[2])][-(SOLO + 60):-SOLO]
 if len(enc) > 2:
     dur = [(e[1] - e[0]) / 1e3 for e in enc]
     gap = [(enc[i + 1][0] - enc[i][1]) / 1e3 for i in range(len(enc) - 1)]
     period = (enc[-1][0] - enc[0][0]) / 1e3 / (len(enc) - 1)
-    solo = [k for k in ks if 'encode_fused' in k[2]][-SOLO:]
+    solo = [k for k in ks if ('encode_fused' in k[2] or 'encode_fast' in k[2])][-SOLO:]
     sd = [(e[1] - e[0]) / 1e3 for e in solo]
     print(f"\nEncoder alone (the {SOLO} reference launches after the timed region): avg {sum(sd) / len(sd):.1f} us.")
     print(f"Steady state (last {len(enc)} encoder launches of the timed region): encoder duration avg {sum(dur) / len(dur):.1f} us "

@@ -111,6 +111,13 @@ int nsc_project_intensity(const float *points, const int64_t *cloud_offsets, int
  * images (n_images, rows, 360), 0 = empty pixel; rows 1..64. */
 int nsc_interpolate_range_images(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,
                                  float *out, void *stream);
+/* The same with the reference's `method` argument: NSC_INTERP_LINEAR (range_image.py:52-64) or NSC_INTERP_NEAREST
+ * (:66-75: the circularly nearest valid pixel of the row, the smaller column on a tie).  NscEncParams.interpolate
+ * takes the same values (0 = off). */
+#define NSC_INTERP_LINEAR 1
+#define NSC_INTERP_NEAREST 2
+int    nsc_interpolate_range_images_ex(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,
+                                       int32_t method, float *out, void *stream);
 
 /* Parity triage: per point, the pixel index row*360+col the scatter uses (-1 = dropped) and
  * whether the exact (float64 atan2) path decided it (bit0 azimuth, bit1 elevation). */
@@ -283,7 +290,8 @@ typedef struct NscMineParams {
     double   negative_distance_max;   /* 50.0  :46 */
     int32_t  positive_temporal_min;   /* 30    :44 */
     int32_t  negative_temporal_min;   /* 30    :47 */
-    int32_t  strategy;                /* 0 = "hard" (argmin W1), 1 = "random" */
+    int32_t  strategy;                /* 0 = "hard" (argmin W1, :347-350), 1 = "random" (:333-334),
+                                       * 2 = "semi-hard" (candidate at position len // 2 of the W1 order, :352-357) */
     int32_t  triplets_per_anchor;
     uint64_t seed;                    /* counter-based choice of the positive (np.random.choice in the reference) */
 } NscMineParams;
@@ -293,6 +301,11 @@ typedef struct NscMineParams {
 int nsc_mine_triplets(const double *positions, const float *cdf, int32_t n, int32_t dim,
                       const NscMineParams *mp, int32_t *out_pos, int32_t *out_neg, int32_t *counts,
                       void *stream);
+/* The same with a workspace: strategy 2 keeps one row of candidate distances per anchor (n * n floats). */
+size_t nsc_mine_workspace_bytes(int32_t n, int32_t strategy);
+int nsc_mine_triplets_ws(const double *positions, const float *cdf, int32_t n, int32_t dim,
+                         const NscMineParams *mp, int32_t *out_pos, int32_t *out_neg, int32_t *counts,
+                         void *ws, size_t ws_bytes, void *stream);
 
 /* Validation recall for loop closure: the pieces of
  * GNNTrainer._compute_recall_loop_closure (reference src/gnn/trainer.py:306-387).

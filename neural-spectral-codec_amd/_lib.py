@@ -98,6 +98,7 @@ SYMBOLS = {
     "nsc_scatter_clouds": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _pp, _vp, _vp]),
     "nsc_finish_images": (C.c_int, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp]),
     "nsc_interpolate_range_images": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "nsc_interpolate_range_images_ex": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "nsc_encode_range_images": (C.c_int, [_vp, _i32, _i32, _pp, _vp, _vp, _vp]),
     "nsc_debug_point_bins": (C.c_int, [_vp, _i64, _i32, _pp, _vp, _vp, _vp]),
     "nsc_graph_workspace_bytes": (_sz, [_i32, _i64]),
@@ -122,6 +123,8 @@ SYMBOLS = {
     "nsc_pairwise_l2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "nsc_recall_rank": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.c_double, _vp, _vp]),
     "nsc_mine_triplets": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(MineParams), _vp, _vp, _vp, _vp]),
+    "nsc_mine_workspace_bytes": (_sz, [_i32, _i32]),
+    "nsc_mine_triplets_ws": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(MineParams), _vp, _vp, _vp, _vp, _sz, _vp]),
     "nsc_topk_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "nsc_topk_smallest": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "nsc_chain_graph_num_edges": (_i64, [_i32, _i32, _i32]),

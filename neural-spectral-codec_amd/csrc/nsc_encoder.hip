@@ -147,7 +147,8 @@ __device__ __forceinline__ void scatter_range(const float *__restrict__ pts, lon
 // ---------------------------------------------------------------------------------------------
 // interpolate one row in LDS (one wavefront)                    range_image.py:33-64
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int interp_row(float *row, int lane, bool do_interp)
+// method: 0 = count the valid pixels only, 1 = circular linear (np.interp, :52-64), 2 = circular nearest (:66-75)
+__device__ __forceinline__ int interp_row(float *row, int lane, int method)
 {
     float v[6];
     unsigned long long m[6];
@@ -160,7 +161,7 @@ __device__ __forceinline__ int interp_row(float *row, int lane, bool do_interp)
     int nv = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) nv += __popcll(m[j]);
-    if (!do_interp || nv == 0 || nv == A) return nv;             // :37-43
+    if (method == 0 || nv == 0 || nv == A) return nv;            // :37-43
 
     const unsigned long long below_mask = (1ull << lane) - 1ull;         // lanes < lane
     const unsigned long long above_mask = ~(below_mask | (1ull << lane)); // lanes > lane
@@ -196,12 +197,21 @@ __device__ __forceinline__ int interp_row(float *row, int lane, bool do_interp)
                 if (jj < j && !fq_found && m[jj]) { q = 64 * jj + __ffsll((long long)m[jj]) - 1 + A; fq_found = true; }
             if (!fq_found) { const unsigned long long b = m[j] & below_mask; q = 64 * j + __ffsll((long long)b) - 1 + A; }
 
-            // np.interp in float64: slope*(x - xp[j]) + fp[j]   (:63, numpy compiled_base.c)
-            const double f0 = (double)row[p < 0 ? p + A : p];
-            const double f1 = (double)row[q >= A ? q - A : q];
-            const double slope = (f1 - f0) / (double)(q - p);
-            const double val = slope * (double)(c - p) + f0;
-            row[c] = (float)val;                                 // :64 store into the float32 image
+            const int vp = p < 0 ? p + A : p, vq = q >= A ? q - A : q;   // the two pixels' own columns
+            if (method == 2) {
+                // nearest valid pixel by circular distance; np.argmin takes the first minimum of the ascending
+                // valid_indices, i.e. the smaller column of two equally near pixels (:68-75)
+                const int dp = c - p, dq = q - c;
+                const int pick = (dp < dq) ? vp : (dq < dp) ? vq : min(vp, vq);
+                row[c] = row[pick];                              // reads original pixels only (pick is valid)
+            } else {
+                // np.interp in float64: slope*(x - xp[j]) + fp[j]   (:63, numpy compiled_base.c)
+                const double f0 = (double)row[vp];
+                const double f1 = (double)row[vq];
+                const double slope = (f1 - f0) / (double)(q - p);
+                const double val = slope * (double)(c - p) + f0;
+                row[c] = (float)val;                             // :64 store into the float32 image
+            }
         }
     }
     return nv;
@@ -456,7 +466,7 @@ __device__ __forceinline__ void finish_image(unsigned char *lds, const EncDev &d
                 }
             }
             wave_sync();
-            const int nv = interp_row(row, lane, d.interp != 0 || mode == 2);
+            const int nv = interp_row(row, lane, mode == 2 ? (d.interp ? d.interp : 1) : d.interp);
             if (lane == 0) rowflag[r] = (nv > 0);
         }
         __syncthreads();
@@ -748,7 +758,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
             }
         }
         wave_sync();
-        const int nv = interp_row(row, lane, d.interp != 0);
+        const int nv = interp_row(row, lane, d.interp);
         if (lane == 0) rowflag[r] = (nv > 0);
     }
     if (tid < TW_N) tw[tid] = twv;
@@ -1300,6 +1310,13 @@ int nsc_encode_range_images(const float *imgs, int32_t n_images, int32_t rows, c
 int nsc_interpolate_range_images(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,
                                  float *out, void *stream_)
 {
+    return nsc_interpolate_range_images_ex(imgs, n_images, rows, lut, NSC_INTERP_LINEAR, out, stream_);
+}
+
+int nsc_interpolate_range_images_ex(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,
+                                    int32_t method, float *out, void *stream_)
+{
+    if (method != NSC_INTERP_LINEAR && method != NSC_INTERP_NEAREST) return NSC_EINVAL;
     if (n_images < 0) return NSC_EINVAL;
     if (rows < 1 || rows > MAXE) return NSC_EUNSUPPORTED;
     if (n_images == 0) return NSC_OK;
@@ -1308,6 +1325,7 @@ int nsc_interpolate_range_images(const float *imgs, int32_t n_images, int32_t ro
     nsc_enc_default_params(&p);
     p.n_elevation = rows;
     p.target_rows = rows < MAXR ? rows : MAXR;
+    p.interpolate = method;
     int st;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const EncDev d = make_dev(&p, rows);

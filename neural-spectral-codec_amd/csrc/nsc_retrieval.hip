@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void topk_stage2_kernel(const float *__restric
 struct MineParams {
     double pos_dmax, neg_dmin, neg_dmax;
     int pos_tmin, neg_tmin;
-    int strategy;              // 0 hard (argmin W1), 1 random
+    int strategy;              // 0 hard (argmin W1), 1 random, 2 semi-hard (median W1)
     int per_anchor;            // triplets per anchor
     unsigned long long seed;
 };
@@ -427,7 +427,8 @@ __device__ __forceinline__ int nth_candidate(int n, int lane, int r, F ok)
 
 __global__ __launch_bounds__(256) void mine_kernel(const double *__restrict__ pos, const float *__restrict__ cdf,
                                                    int n, int D, MineParams p, int *__restrict__ out_pos,
-                                                   int *__restrict__ out_neg, int *__restrict__ counts)
+                                                   int *__restrict__ out_neg, int *__restrict__ counts,
+                                                   float *__restrict__ ws)
 {
     const int lane = threadIdx.x & 63, la = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (la >= n) return;
@@ -474,6 +475,46 @@ __global__ __launch_bounds__(256) void mine_kernel(const double *__restrict__ po
                 if (s < best) { best = s; hard = cand; }
             }
         }
+    }
+    if (p.strategy == 2) {
+        // semi-hard (:352-357): the candidate at position len // 2 of the candidates sorted by W1.  The distances of
+        // this anchor's candidates go to its row of the workspace (+inf elsewhere); the value of that rank is found
+        // by bisection on the float bits (distances are >= 0: unsigned order == float order), ties resolve to the
+        // smaller index (np.argsort's quicksort leaves the order of exact ties undefined).
+        float *row = ws + (long long)la * n;
+        const float *ca = cdf + (long long)la * D;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int lo = c0 + lane;
+            unsigned long long m = __ballot(lo < n && is_neg(lo));
+            if (lo < n) row[lo] = INFINITY;
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float *cb = cdf + (long long)(c0 + b) * D;
+                float sd = 0.0f;
+                for (int c = lane; c < D; c += 64) sd += fabsf(ca[c] - cb[c]);
+                sd = wave_sumf(sd);
+                if (lane == b) row[c0 + b] = sd;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the wave re-reads its own row across lanes
+        const int k = nneg / 2;
+        unsigned lo_b = 0u, hi_b = 0x7f800000u;                      // smallest v with #(d <= v) >= k + 1
+        while (lo_b < hi_b) {
+            const unsigned mid = lo_b + (hi_b - lo_b) / 2u;
+            int cnt = 0;
+            for (int c0 = 0; c0 < n; c0 += 64) {
+                const int lo = c0 + lane;
+                cnt += __popcll(__ballot(lo < n && __float_as_uint(row[lo]) <= mid));
+            }
+            if (cnt >= k + 1) hi_b = mid; else lo_b = mid + 1u;
+        }
+        int less = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int lo = c0 + lane;
+            less += __popcll(__ballot(lo < n && __float_as_uint(row[lo]) < lo_b));
+        }
+        hard = nth_candidate(n, lane, k - less, [&](int lo) { return __float_as_uint(row[lo]) == lo_b; });
     }
     for (int k = 0; k < p.per_anchor; ++k) {           // :211-216
         const int rp = (int)(mine_hash(p.seed, (unsigned)la, 2u * k) % (unsigned)npos);
@@ -648,11 +689,24 @@ int nsc_recall_rank(const double *positions, const int32_t *query_idx, const int
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 
+size_t nsc_mine_workspace_bytes(int32_t n, int32_t strategy)
+{
+    return (strategy == 2 && n > 0) ? (size_t)n * (size_t)n * sizeof(float) : 0;
+}
+
 int nsc_mine_triplets(const double *positions, const float *cdf, int32_t n, int32_t D, const NscMineParams *mp,
                       int32_t *out_pos, int32_t *out_neg, int32_t *counts, void *stream_)
 {
+    if (mp && mp->strategy == 2) return NSC_EWORKSPACE;          // semi-hard needs nsc_mine_triplets_ws
+    return nsc_mine_triplets_ws(positions, cdf, n, D, mp, out_pos, out_neg, counts, nullptr, 0, stream_);
+}
+
+int nsc_mine_triplets_ws(const double *positions, const float *cdf, int32_t n, int32_t D, const NscMineParams *mp,
+                         int32_t *out_pos, int32_t *out_neg, int32_t *counts, void *ws, size_t ws_bytes, void *stream_)
+{
     if (!mp || n < 0 || D < 1) return NSC_EINVAL;
-    if (mp->strategy != 0 && mp->strategy != 1) return NSC_EUNSUPPORTED;
+    if (mp->strategy < 0 || mp->strategy > 2) return NSC_EUNSUPPORTED;
+    if (mp->strategy == 2 && n > 0 && (!ws || ws_bytes < nsc_mine_workspace_bytes(n, 2))) return NSC_EWORKSPACE;
     if (mp->triplets_per_anchor < 1) return NSC_EINVAL;
     if (n == 0) return NSC_OK;
     if (!positions || !cdf || !out_pos || !out_neg || !counts) return NSC_EINVAL;
@@ -661,7 +715,7 @@ int nsc_mine_triplets(const double *positions, const float *cdf, int32_t n, int3
     p.pos_tmin = mp->positive_temporal_min; p.neg_tmin = mp->negative_temporal_min;
     p.strategy = mp->strategy; p.per_anchor = mp->triplets_per_anchor; p.seed = mp->seed;
     hipLaunchKernelGGL(mine_kernel, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), positions, cdf, n, D,
-                       p, out_pos, out_neg, counts);
+                       p, out_pos, out_neg, counts, static_cast<float *>(ws));
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

@@ -101,10 +101,12 @@ def project_to_range_image(points: np.ndarray, n_elevation: int = 64, n_azimuth:
 
 def interpolate_range_image(range_image: np.ndarray, method: str = "linear",
                             device="cuda") -> np.ndarray:
-    """range_image.py:15-89 (method='linear') on the device: (rows, 360) image with 0 for empty pixels
-    -> interpolated image, bit-identical to the reference (nsc_interpolate_range_images)."""
-    if method != "linear":
-        raise NotImplementedError("only method='linear' is used by the reference (spectral_encoder.py:221)")
+    """range_image.py:15-89 on the device: (rows, 360) image with 0 for empty pixels -> interpolated image,
+    bit-identical to the reference, method 'linear' (:52-64) or 'nearest' (:66-75)
+    (nsc_interpolate_range_images_ex)."""
+    if method not in ("linear", "nearest"):
+        # (the reference silently skips the column interpolation for any other string and only copies empty rows)
+        raise ValueError(f"method must be 'linear' or 'nearest', got {method!r}")
     from .spectral_encoder import _default_lut
     dev = torch.device(device)
     img = torch.as_tensor(np.ascontiguousarray(range_image, dtype=np.float32)).to(dev)
@@ -114,9 +116,9 @@ def interpolate_range_image(range_image: np.ndarray, method: str = "linear",
         raise ValueError("range images must have 360 azimuth columns")
     out = torch.empty_like(x)
     with torch.cuda.device(dev):
-        st = _lib.lib().nsc_interpolate_range_images(_lib.ptr(x), int(x.shape[0]), int(x.shape[1]),
-                                                     _lib.ptr(_default_lut(dev)), _lib.ptr(out),
-                                                     _lib.stream_ptr(dev))
-    _lib.check(st, "nsc_interpolate_range_images")
+        st = _lib.lib().nsc_interpolate_range_images_ex(_lib.ptr(x), int(x.shape[0]), int(x.shape[1]),
+                                                        _lib.ptr(_default_lut(dev)), 1 if method == "linear" else 2,
+                                                        _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(st, "nsc_interpolate_range_images_ex")
     res = out if batched else out[0]
     return res.cpu().numpy()

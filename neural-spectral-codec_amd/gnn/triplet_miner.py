@@ -5,7 +5,8 @@
 The reference walks the anchors in Python, asks a cKDTree three radius questions per anchor and calls
 ``wasserstein_distance_1d_numpy`` once per negative candidate.  Here one kernel (nsc_mine_triplets, one
 wavefront per anchor) evaluates the same inclusive-radius / temporal-gap predicates by brute force with
-float64 distances and picks argmin W1 over the candidates from pre-normalised CDF rows.
+float64 distances and picks argmin W1 over the candidates from pre-normalised CDF rows ("hard"; "semi-hard" takes the
+candidate at position len // 2 of the W1 order, :352-357, "random" a uniform one).
 The positive is a uniform random candidate (``np.random.choice`` in the reference, unseeded): chosen
 here by a counter-based hash seeded from numpy's global RNG, so ``np.random.seed`` still controls it.
 """
@@ -30,9 +31,8 @@ class TripletMiner:
         self.negative_temporal_min = negative_temporal_min
         self.mining_strategy = mining_strategy
         self.device = torch.device(device)
-        if mining_strategy not in ("hard", "random"):
-            raise NotImplementedError("mining_strategy 'semi-hard' is not on the device path "
-                                      "(the reference configs use 'hard')")
+        if mining_strategy not in ("hard", "random", "semi-hard"):
+            raise ValueError(f"Unknown mining strategy: {mining_strategy}")                  # :359
 
     def _params(self, per_anchor: int) -> _lib.MineParams:
         p = _lib.MineParams()
@@ -41,7 +41,7 @@ class TripletMiner:
         p.negative_distance_max = float(self.negative_distance_max)
         p.positive_temporal_min = int(self.positive_temporal_min)
         p.negative_temporal_min = int(self.negative_temporal_min)
-        p.strategy = 0 if self.mining_strategy == "hard" else 1
+        p.strategy = {"hard": 0, "random": 1, "semi-hard": 2}[self.mining_strategy]
         p.triplets_per_anchor = int(per_anchor)
         p.seed = int(np.random.randint(0, 2 ** 62, dtype=np.int64))
         return p
@@ -59,11 +59,14 @@ class TripletMiner:
         out_neg = torch.empty_like(out_pos)
         counts = torch.empty((n, 2), dtype=torch.int32, device=dev)
         p = self._params(n_triplets_per_anchor)
+        L = _lib.lib()
+        nbytes = L.nsc_mine_workspace_bytes(n, p.strategy)       # semi-hard: one row of candidate distances per anchor
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
         with torch.cuda.device(dev):
-            st = _lib.lib().nsc_mine_triplets(_lib.ptr(pos), _lib.ptr(cdf), n, int(desc.shape[1]), C.byref(p),
-                                              _lib.ptr(out_pos), _lib.ptr(out_neg), _lib.ptr(counts),
-                                              _lib.stream_ptr(dev))
-        _lib.check(st, "nsc_mine_triplets")
+            st = L.nsc_mine_triplets_ws(_lib.ptr(pos), _lib.ptr(cdf), n, int(desc.shape[1]), C.byref(p),
+                                        _lib.ptr(out_pos), _lib.ptr(out_neg), _lib.ptr(counts), _lib.ptr(ws), nbytes,
+                                        _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_mine_triplets_ws")
         ok = (out_pos >= 0) & (out_neg >= 0)
         a_loc = torch.arange(n, device=dev).unsqueeze(1).expand_as(out_pos)[ok]
         trip = torch.stack([idx[a_loc], idx[out_pos[ok].long()], idx[out_neg[ok].long()]], 1)

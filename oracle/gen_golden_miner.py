@@ -26,6 +26,8 @@ np.random.seed(0)
 trip = np.array(TripletMiner().mine_triplets(desc, poses, 1, seq))
 np.random.seed(1)
 trip2 = np.array(TripletMiner().mine_triplets(desc, poses, 2, seq))
-print(trip.shape, trip2.shape, trip[:5])
+np.random.seed(2)
+trip_semi = np.array(TripletMiner(mining_strategy="semi-hard").mine_triplets(desc, poses, 1, seq))   # :352-357
+print(trip.shape, trip2.shape, trip_semi.shape, trip[:5])
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "miner.npz"), poses=poses, seq=seq, desc=desc,
-                    triplets=trip, triplets2=trip2)
+                    triplets=trip, triplets2=trip2, triplets_semi=trip_semi)

@@ -38,3 +38,8 @@ def mine_sequence(descriptors, positions, **kw):
         dist = np.array([w1_numpy(descriptors[la], descriptors[j]) for j in neg])       # :339-345
         out.append((pos, neg, int(neg[np.argmin(dist)]), dist))
     return out
+
+
+def semi_hard(neg, dist):
+    """mining_strategy='semi-hard' (triplet_miner.py:352-357): the candidate at position len // 2 of the W1 order."""
+    return int(neg[np.argsort(dist)[len(dist) // 2]])

@@ -124,6 +124,32 @@ def project_intensity(points, p=None):
     return img, out.reshape(img.shape)
 
 
+def interpolate_nearest(img):
+    """interpolate_range_image(img, 'nearest'), range_image.py:33-47 + :66-87, in numpy (TEST INFRASTRUCTURE; pinned
+    by tests/golden/interp_nearest.npz, generated from the reference by oracle/gen_golden_nearest.py)."""
+    out = np.array(img, dtype=np.float32, copy=True)
+    E, A = out.shape
+    for r in range(E):
+        row = out[r]
+        valid = np.where(row > 0)[0]
+        if len(valid) == 0 or len(valid) == A:
+            continue
+        vals = row.copy()
+        for c in np.where(~(row > 0))[0]:
+            d = np.minimum(np.abs(valid - c), A - np.abs(valid - c))     # :69-72
+            out[r, c] = vals[valid[np.argmin(d)]]                        # first minimum = smaller column on a tie
+    for r in range(E):                                                   # :77-87
+        if not np.any(out[r] > 0):
+            for k in range(1, E):
+                if r - k >= 0 and np.any(out[r - k] > 0):
+                    out[r] = out[r - k]
+                    break
+                if r + k < E and np.any(out[r + k] > 0):
+                    out[r] = out[r + k]
+                    break
+    return out
+
+
 def interpolate(img):
     out = np.ascontiguousarray(img, dtype=np.float32).copy()
     lib().nsc_oracle_interpolate(_f(out), out.shape[0], out.shape[1])

@@ -232,6 +232,19 @@ def test_interpolate_range_image_standalone(path):
     assert np.array_equal(out.view(np.uint32), g["ref_interp"])
 
 
+def test_interpolate_range_image_nearest(golden_dir):
+    """method='nearest' (range_image.py:66-75): circularly nearest valid pixel, smaller column on a tie; bit for bit
+    against the reference's outputs, single image and batched."""
+    from neural_spectral_codec_amd.encoding.range_image import interpolate_range_image
+    g = np.load(os.path.join(golden_dir, "interp_nearest.npz"))
+    raw = g["raw"].view(np.float32)
+    for im, want in zip(raw, g["nearest"]):
+        assert np.array_equal(interpolate_range_image(im, method="nearest").view(np.uint32), want)
+    assert np.array_equal(interpolate_range_image(raw, method="nearest").view(np.uint32), g["nearest"])
+    with pytest.raises(ValueError):
+        interpolate_range_image(raw[0], method="cubic")
+
+
 def test_projector_project_matches_reference(golden_dir):
     from neural_spectral_codec_amd.encoding.range_image import RangeImageProjector
     g = np.load(os.path.join(golden_dir, "enc_uniform20k.npz"))

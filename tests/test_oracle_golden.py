@@ -123,3 +123,11 @@ def test_intensity_oracle_matches_reference():
         assert (img.view(np.uint32) == g[k + "_range"].view(np.uint32)).all(), k
         assert (inten.view(np.uint32) == g[k + "_intensity"].view(np.uint32)).all(), k
         assert inten.min() >= 0.0 and (inten > 0).sum() > 1000
+
+
+def test_nearest_interpolation_oracle_matches_reference(golden_dir):
+    """interpolate_range_image(method='nearest') (range_image.py:66-87): numpy restatement vs the reference's outputs."""
+    g = np.load(os.path.join(golden_dir, "interp_nearest.npz"))
+    for raw, want in zip(g["raw"], g["nearest"]):
+        got = orc.interpolate_nearest(raw.view(np.float32))
+        assert np.array_equal(got.view(np.uint32), want)

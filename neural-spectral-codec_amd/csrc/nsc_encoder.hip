@@ -44,6 +44,7 @@ struct EncDev {
     int interp;
 #ifdef NSC_DEV_TUNING
     int dev_skip;          // development builds only (NSC_TUNE_SKIP_FINISH): phase masks for tools/ab_enc.py
+    int dev_stagger;       // development: start delay per CU slot, in units of 64 clocks (NSC_TUNE_STAGGER)
 #endif
 };
 
@@ -696,6 +697,14 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
             NSC_SLOT_LOAD(slot, a);
         });
         o += RB;
+        // Keep the four waves of a cloud in step: one s_barrier per round (it waits for no memory counter, the loads
+        // stay in flight across it).  Waves that drift apart turn the workgroup's 32 KB-per-round sequential sweep into
+        // four unrelated streams; in step, the same kernel measured 2.2-2.7 % faster (interleaved A/B, round 2) and the
+        // four waves also reach the finish together.  Every wave runs the same number of rounds (T depends on n only).
+#ifdef NSC_DEV_TUNING
+        if (!(dev_mode & 256))
+#endif
+        __builtin_amdgcn_s_barrier();
     }
     if (T >= 2) {                                // round T - 2: its refill is the last, possibly partial, round
         static_for<U>([&](auto uc) {
@@ -724,8 +733,9 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
 #endif
 }
 
-__device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d, float *__restrict__ out_desc,
-                                            float *__restrict__ out_raw, float *__restrict__ out_interp)
+__device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d, const int *__restrict__ lut,
+                                            float *__restrict__ out_desc, float *__restrict__ out_raw,
+                                            float *__restrict__ out_interp)
 {
     constexpr int NW = 4, NT = 256, E = 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -733,7 +743,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
     const FastLds lp = fast_lds(B);
     float *img = reinterpret_cast<float *>(lds + lp.img);
     double2 *tw = reinterpret_cast<double2 *>(lds + lp.aux);
-    const int *seg = reinterpret_cast<const int *>(lds + lp.seg);
+    int *seg = reinterpret_cast<int *>(lds + lp.seg);
     double *rowsum = reinterpret_cast<double *>(lds + lp.misc);
     int *rowflag = reinterpret_cast<int *>(lds + lp.misc + MAXR * 8);
     int *rowsrc = rowflag + 16;
@@ -741,6 +751,10 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
     // the twiddle table replaces the (drained) queue; its global loads land under the sqrt / interpolation below
     double2 twv = {0.0, 0.0};
     if (tid < TW_N) twv = g_tw360[tid];
+    // histogram segments (see setup_tables): bin b owns the frequencies [seg[b], seg[B + b]).  One round of loads, no
+    // dependent search: thread k sees where the monotone LUT steps at frequency k and writes the bins that start there.
+    int lut_prev = -1, lut_cur = -1;
+    if (tid < F) { lut_cur = lut[tid]; lut_prev = tid ? lut[tid - 1] : -1; }
 
     const int r0 = 4 * wave;                                      // this wave owns rows r0 .. r0 + 3
     for (int r = r0; r < r0 + 4; ++r) {
@@ -762,6 +776,12 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
         if (lane == 0) rowflag[r] = (nv > 0);
     }
     if (tid < TW_N) tw[tid] = twv;
+    if (tid < F) {
+        lut_cur = min(lut_cur, B - 1);
+        for (int b = lut_prev + 1; b <= lut_cur; ++b) { seg[b] = tid; if (b > 0) seg[B + b - 1] = tid; }
+        if (tid == F - 1)
+            for (int b = lut_cur; b < B; ++b) { seg[B + b] = F; if (b > lut_cur) seg[b] = F; }
+    }
     __syncthreads();
     if (d.interp) {                                               // range_image.py:77-87
         unsigned ne = 0u;
@@ -861,18 +881,14 @@ __global__ __launch_bounds__(256, 4) void encode_fast_kernel(
         if (tid == 0) *qcount = 0u;
     }
     __syncthreads();
-    if (tid >= NT - 64) {                    // last wave: histogram segments (see setup_tables), then joins the stream
-        int *seg = reinterpret_cast<int *>(lds + lp.seg);
-        const int B = d.B;
-        for (int b = tid - (NT - 64); b < 2 * B; b += 64) {
-            const int key = (b < B) ? b : b - B + 1;
-            int l = 0, h = F;
-            while (l < h) { const int m = (l + h) >> 1; if (lut[m] >= key) h = m; else l = m + 1; }
-            seg[b] = l;
-        }
-    }
     const long long p0 = off[c];
     const int n = (int)(off[c + 1] - p0);                           // < 2^27 (host check)
+#ifdef NSC_DEV_TUNING
+    if (d.dev_stagger > 0) {          // workgroups b, b + 256, b + 512, b + 768 are expected to share a CU
+        const int units = ((blockIdx.x >> 8) & 3) * d.dev_stagger;
+        for (int u = 0; u < units; u += 100) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
     if (n > 0 && !NSC_DEV_SKIP(d, 2))
 #ifdef NSC_DEV_TUNING
         stream_fast<NT, U>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount, d.dev_skip);
@@ -900,7 +916,7 @@ __global__ __launch_bounds__(256, 4) void encode_fast_kernel(
         return;
     }
     const long long D = 16LL * d.B;
-    finish_fast(lds, d, out_desc + c * D, out_raw ? out_raw + (long long)c * 16 * A : nullptr,
+    finish_fast(lds, d, lut, out_desc + c * D, out_raw ? out_raw + (long long)c * 16 * A : nullptr,
                 out_interp ? out_interp + (long long)c * 16 * A : nullptr);
 }
 
@@ -1069,6 +1085,7 @@ EncDev make_dev(const NscEncParams *p, int rows_in)
     d.interp = p->interpolate;
 #ifdef NSC_DEV_TUNING
     d.dev_skip = tune_env("NSC_TUNE_SKIP_FINISH", 0);
+    d.dev_stagger = tune_env("NSC_TUNE_STAGGER", 0);
 #endif
     return d;
 }

@@ -639,27 +639,34 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
 // "+v" operand of BOTH statements, so the compiler holds it in one register quad and never reads it between the load
 // and the wait; every statement is volatile with a memory clobber (program order is kept); the last round issues no
 // loads and counts its waits down to vmcnt(0), so nothing is in flight when the registers are reused.
-template <int NT, int U>
+template <int NT, int U, bool PAIR = true>
 __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, int tid, const NscBinParams &bp,
                                             unsigned *img, f32x4 *queue, unsigned *qcount, int dev_mode = 0)
 {
 #ifdef NSC_DEV_TUNING
     float dev_acc = 0.f;
 #endif
-    auto process = [&](const f32x4 &v) {
+    auto park = [&](const f32x4 &v, float s) {                       // ~2e-4 of the points
+        const unsigned slot = atomicAdd(qcount, 1u);                 // counts past FQ_CAP: the kernel then re-streams
+        if (slot < (unsigned)FQ_CAP) queue[slot] = f32x4{v.x, v.y, v.z, s};
+    };
+    // two slots at a time: the lean estimate of both points in packed float32 instructions (nsc_point_lean_pair)
+    auto process2 = [&](const f32x4 &va, const f32x4 &vb) {
 #ifdef NSC_DEV_TUNING
-        if (dev_mode & 64) { dev_acc += v.x + v.y + v.z; return; }           // loads only
+        if (dev_mode & 64) { dev_acc += (va.x + va.y + va.z) + (vb.x + vb.y + vb.z); return; }   // loads only
 #endif
-        int pix; float s; bool certain;
-        if (!nsc_point_lean_flags(v.x, v.y, v.z, bp, pix, s, certain)) return;
+        const NscLeanPair p = nsc_point_lean_pair(va.x, va.y, va.z, vb.x, vb.y, vb.z, bp);
 #ifdef NSC_DEV_TUNING
-        if (dev_mode & 128) { dev_acc += (float)(pix + (int)certain) + s; return; }   // loads + binning, no LDS atomics
+        if (dev_mode & 128) {                                                    // loads + binning, no LDS atomics
+            dev_acc += (float)(p.pix[0] + (int)p.ok[0] + p.pix[1] + (int)p.ok[1]) + p.s[0] + p.s[1] + (float)(p.park[0] | p.park[1]);
+            return;
+        }
 #endif
-        if (certain) {
-            atomicMin(&img[pix], __float_as_uint(s));                // ds_min_u32 (s >= 0: uint order == float order)
-        } else {                                                     // ~2e-4 of the points
-            const unsigned slot = atomicAdd(qcount, 1u);             // counts past FQ_CAP: the kernel then re-streams
-            if (slot < (unsigned)FQ_CAP) queue[slot] = f32x4{v.x, v.y, v.z, s};
+        if (p.ok[0]) atomicMin(&img[p.pix[0]], __float_as_uint(p.s[0]));   // ds_min_u32 (s >= 0: uint order == float order)
+        if (p.ok[1]) atomicMin(&img[p.pix[1]], __float_as_uint(p.s[1]));
+        if (p.park[0] | p.park[1]) {
+            if (p.park[0]) park(va, p.s[0]);
+            if (p.park[1]) park(vb, p.s[1]);
         }
     };
     // wave-uniform base address in SGPRs + a 32-bit byte offset per lane (clouds hold < 2^27 points)
@@ -674,7 +681,7 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
     // (the operands are local references: clang does not capture a variable that only an asm operand names)
 #define NSC_SLOT_LOAD(slot, ofs)                                                                                  \
     asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(slot) : "v"(ofs), "s"(base_) : "memory")
-#define NSC_SLOT_WAIT(slot, cnt) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "i"(cnt) : "memory")
+#define NSC_SLOT_WAIT2(s0, s1, cnt) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s0), "+v"(s1) : "i"(cnt) : "memory")
 
     unsigned o = (unsigned)tid * 16u;                               // byte offset of slot 0 of the current round
     static_for<U>([&](auto uc) {
@@ -686,15 +693,28 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
         NSC_SLOT_LOAD(slot, a);
     });
     constexpr unsigned RB = (unsigned)(U * NT * 16);                 // bytes per round
+    static_assert(U % 2 == 0, "slots are binned in pairs");
+#ifdef NSC_DEV_TUNING
+    // development A/B (NSC_TUNE_VARIANT=-4): one point at a time through the scalar nsc_point_lean_flags
+    auto process1 = [&](const f32x4 &v) {
+        int pix; float s; bool certain;
+        if (!nsc_point_lean_flags(v.x, v.y, v.z, bp, pix, s, certain)) return;
+        if (certain) atomicMin(&img[pix], __float_as_uint(s)); else park(v, s);
+    };
+#define NSC_PROCESS2(a, b) do { if constexpr (PAIR) process2(a, b); else { process1(a); process1(b); } } while (0)
+#else
+#define NSC_PROCESS2(a, b) process2(a, b)
+#endif
     for (int r = 0; r + 2 < T; ++r) {            // rounds whose refill (round r + 1) is complete: no clamping
-        static_for<U>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            f32x4 &slot = buf[u];
+        static_for<U / 2>([&](auto uc) {
+            constexpr int u = 2 * decltype(uc)::value;
+            f32x4 &slot = buf[u], &slot1 = buf[u + 1];
             const unsigned long long base_ = Pb;
-            NSC_SLOT_WAIT(slot, U - 1);
-            process(slot);
-            const unsigned a = o + RB + (unsigned)(u * NT * 16);
+            NSC_SLOT_WAIT2(slot, slot1, U - 2);
+            NSC_PROCESS2(slot, slot1);
+            const unsigned a = o + RB + (unsigned)(u * NT * 16), a1 = a + (unsigned)(NT * 16);
             NSC_SLOT_LOAD(slot, a);
+            NSC_SLOT_LOAD(slot1, a1);
         });
         o += RB;
         // Keep the four waves of a cloud in step: one s_barrier per round (it waits for no memory counter, the loads
@@ -707,27 +727,31 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
         __builtin_amdgcn_s_barrier();
     }
     if (T >= 2) {                                // round T - 2: its refill is the last, possibly partial, round
-        static_for<U>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            f32x4 &slot = buf[u];
+        static_for<U / 2>([&](auto uc) {
+            constexpr int u = 2 * decltype(uc)::value;
+            f32x4 &slot = buf[u], &slot1 = buf[u + 1];
             const unsigned long long base_ = Pb;
-            NSC_SLOT_WAIT(slot, U - 1);
-            process(slot);
+            NSC_SLOT_WAIT2(slot, slot1, U - 2);
+            NSC_PROCESS2(slot, slot1);
             const unsigned a = min(o + RB + (unsigned)(u * NT * 16), last);
+            const unsigned a1 = min(o + RB + (unsigned)((u + 1) * NT * 16), last);
             NSC_SLOT_LOAD(slot, a);
+            NSC_SLOT_LOAD(slot1, a1);
         });
         o += RB;
     }
-    static_for<U>([&](auto uc) {                 // last round: no refills, waits count down to vmcnt(0)
-        constexpr int u = decltype(uc)::value;
-        f32x4 &slot = buf[u];
-        NSC_SLOT_WAIT(slot, U - 1 - u);
-        f32x4 v = slot;
+    static_for<U / 2>([&](auto uc) {             // last round: no refills, waits count down to vmcnt(0)
+        constexpr int u = 2 * decltype(uc)::value;
+        f32x4 &slot = buf[u], &slot1 = buf[u + 1];
+        NSC_SLOT_WAIT2(slot, slot1, U - 2 - u);
+        f32x4 v = slot, v1 = slot1;
         if (o + (unsigned)(u * NT * 16) > last) v.x = NAN;          // past the cloud: fails the range window
-        process(v);
+        if (o + (unsigned)((u + 1) * NT * 16) > last) v1.x = NAN;
+        NSC_PROCESS2(v, v1);
     });
+#undef NSC_PROCESS2
+#undef NSC_SLOT_WAIT2
 #undef NSC_SLOT_LOAD
-#undef NSC_SLOT_WAIT
 #ifdef NSC_DEV_TUNING
     if (dev_mode & (64 | 128)) atomicMin(&img[tid & 63], __float_as_uint(fabsf(dev_acc)));
 #endif
@@ -862,7 +886,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
     }
 }
 
-template <int U>
+template <int U, bool PAIR = true>
 __global__ __launch_bounds__(256, 4) void encode_fast_kernel(
     const float *__restrict__ pts, const long long *__restrict__ off, EncDev d, const int *__restrict__ lut,
     float *__restrict__ out_desc, float *__restrict__ out_raw, float *__restrict__ out_interp)
@@ -891,9 +915,9 @@ __global__ __launch_bounds__(256, 4) void encode_fast_kernel(
 #endif
     if (n > 0 && !NSC_DEV_SKIP(d, 2))
 #ifdef NSC_DEV_TUNING
-        stream_fast<NT, U>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount, d.dev_skip);
+        stream_fast<NT, U, PAIR>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount, d.dev_skip);
 #else
-        stream_fast<NT, U>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount);
+        stream_fast<NT, U, PAIR>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount);
 #endif
     __syncthreads();
     {   // drain the uncertain-point queue with the exact chain (the definition of the pixel), compacted
@@ -1028,8 +1052,14 @@ __global__ __launch_bounds__(256) void point_bins_kernel(
          i += (long long)gridDim.x * blockDim.x) {
         const float x = pts[i * stride], y = pts[i * stride + 1], z = pts[i * stride + 2];
         int pix; float s;
-        if (lean) {            // what encode_fast_kernel does with a point: lean estimate, exact chain when uncertain
-            const int st = nsc_point_lean(x, y, z, bp, pix, s);
+        if (lean) {            // what encode_fast_kernel does with a point: lean estimate (the packed two-point form,
+                               // here with the point in both halves swapped by parity), exact chain when uncertain
+            const float xn = pts[(i ^ 1) < n ? (i ^ 1) * stride : i * stride], yn = pts[((i ^ 1) < n ? (i ^ 1) : i) * stride + 1],
+                        zn = pts[((i ^ 1) < n ? (i ^ 1) : i) * stride + 2];
+            const int h = (int)(i & 1);
+            const NscLeanPair p = h ? nsc_point_lean_pair(xn, yn, zn, x, y, z, bp) : nsc_point_lean_pair(x, y, z, xn, yn, zn, bp);
+            const int st = p.ok[h] ? 1 : p.park[h] ? 2 : 0;
+            pix = p.pix[h];
             if (st == 2) pix = nsc_point_exact(x, y, z, bp);
             out_idx[i] = st ? pix : -1;
             if (out_flags) out_flags[i] = (unsigned char)(st == 2 ? 3 : 0);
@@ -1176,6 +1206,7 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
         if (variant <= 0 && stride == 4 && d.E == 16 && d.R == 16 && d.B <= FAST_HSTRIDE && nsc_lean_ok(d.bp) &&
             total_points < FAST_MAX_POINTS) {
             const FastLds fl = fast_lds(d.B);
+#ifdef NSC_DEV_TUNING
             if (variant == -1)
                 hipLaunchKernelGGL(encode_fast_kernel<4>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
                                    out_desc, out_raw, out_interp);
@@ -1185,7 +1216,11 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
             else if (variant == -3)
                 hipLaunchKernelGGL(encode_fast_kernel<12>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
                                    out_desc, out_raw, out_interp);
+            else if (variant == -4)
+                hipLaunchKernelGGL((encode_fast_kernel<8, false>), dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d,
+                                   lut, out_desc, out_raw, out_interp);
             else
+#endif
                 hipLaunchKernelGGL(encode_fast_kernel<8>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
                                    out_desc, out_raw, out_interp);
             return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;

@@ -278,6 +278,56 @@ NSC_HD int nsc_mul24(int a, int b)
 #endif
 }
 
+// max / min of |x| and |y|: on the device one VOP3 instruction each with |.| source modifiers (fmaxf(fabsf, fabsf)
+// compiles to two extra canonicalising v_max_f32 under IEEE mode)
+NSC_HD float nsc_absmax(float x, float y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#else
+    return fmaxf(fabsf(x), fabsf(y));
+#endif
+}
+
+NSC_HD float nsc_absmin(float x, float y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#else
+    return fminf(fabsf(x), fabsf(y));
+#endif
+}
+
+NSC_HD float nsc_absdiff(float x, float y)      // |x| - |y|
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_sub_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#else
+    return fabsf(x) - fabsf(y);
+#endif
+}
+
+// First-octant angle q = atan(min/max) in degrees, [0,45]  ->  column coordinate (atan2(y,x) + 180 deg), [0,360], with
+// three sign transfers (v_bfi_b32) instead of three compare/subtract/select triples on the integer column:
+//   a1 = |x| < |y| ? 90 - q : q;   a2 = x < 0 ? 180 - a1 : a1;   result = y < 0 ? 180 - a2 : 180 + a2.
+// The four float additions round by at most 2^-19 + 2^-18 + 2^-17 + 2^-16 < 2.9e-5 columns in total, less than the
+// 4e-5 (NSC_AZ_EST_ERR, part of az_delta) by which a CERTAIN q stays clear of every integer: truncating the result
+// gives the same column as unfolding (int)q.  Zero coordinates of either sign give q = 0 or NaN: never certain.
+NSC_HD float nsc_unfold_octant(float q, float x, float y)
+{
+    const float d = nsc_absdiff(x, y);                         // sign set <=> |x| < |y| (the two octants that swap)
+    const float c = 45.0f - q;
+    const float b = 45.0f + __builtin_copysignf(c, d);         // 90 - a1
+    const float a2 = 90.0f - __builtin_copysignf(b, x);
+    return 180.0f + __builtin_copysignf(a2, y);
+}
+
 // Returns false if the point is dropped; else `certain` says whether (pix, s) is final or pix only the estimate.
 NSC_HD bool nsc_point_lean_flags(float x, float y, float z, const NscBinParams &bp, int &pix, float &s, bool &certain)
 {
@@ -286,27 +336,108 @@ NSC_HD bool nsc_point_lean_flags(float x, float y, float z, const NscBinParams &
     certain = false;
     if (!(s >= bp.s_lo && s <= bp.s_hi)) return false;                // :151-155, :174-177 (inf/NaN fall out here)
     // column: octant reduction + degree-7 minimax atan, in columns
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float q = nsc_atan01_deg(mn * nsc_rcp_approx(mx));          // [0,45]; NaN for x = y = 0 -> uncertain
+    const float q = nsc_atan01_deg(nsc_absmin(x, y) * nsc_rcp_approx(nsc_absmax(x, y)));   // [0,45]; NaN for x = y = 0
     const float gc = nsc_fractf(q) - 0.5f;
-    const int iq = (int)q;                                            // q >= 0: truncation == floor
-    int ib = (ax >= ay) ? iq : 89 - iq;
-    ib = (x < 0.0f) ? 179 - ib : ib;
-    const int col = (y < 0.0f) ? 179 - ib : 180 + ib;
     const bool cok = fabsf(gc) < (0.5f - NSC_LEAN_GUARD) - bp.az_delta;
-    // row: t = z / rxy from v_rsq_f32, degree-5 atan, affine map to rows, clamp so that out-of-FOV rows are certain
+    const int col = (int)nsc_unfold_octant(q, x, y);                  // garbage when !cok (never used then)
+    // row: t = z / rxy from v_rsq_f32, degree-5 atan, affine map to rows; clamped so that out-of-FOV rows are certain
+    // (f = 1/2 at both ends) and the truncation below lands in [0, E - 1]
     const float t = nsc_clampf(z * nsc_rsq_approx(sxy), -0.62f, 0.62f);
     const float u = nsc_clampf(__builtin_fmaf(nsc_atan_small(t), bp.el_u_scale, bp.el_u_bias), -0.5f,
-                               (float)bp.E + 0.5f);
+                               (float)bp.E - 0.5f);
     const float gr = nsc_fractf(u) - 0.5f;
-    int row = (int)u;                                                 // u in [-0.5, E + 0.5]: (-0.5, 0) truncates to row 0
-    row = row > bp.E - 1 ? bp.E - 1 : row;
+    const int row = (int)u;                                           // u in [-0.5, E - 0.5]: (-0.5, 0) truncates to row 0
     const bool rok = fabsf(gr) < (0.5f - NSC_LEAN_GUARD) - bp.el_delta;
     pix = nsc_mul24(row, NSC_A) + col;
     certain = cok && rok;
     return true;
 }
+
+#if defined(__HIPCC__)
+// Two points at once: the same operations in the same order as nsc_point_lean_flags on each point, with the
+// multiplies, adds and FMAs of the two points in the two halves of gfx950's packed float32 instructions
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per lane and issue slot, each rounded exactly like
+// its scalar form) -- ~26 of the ~55 VALU instructions per point are shared by the pair.  Nothing is skipped for a
+// dropped point (its results are simply not used), so the range test moves from a branch to two flags.
+typedef float nsc_f32x2 __attribute__((ext_vector_type(2)));
+
+struct NscLeanPair {
+    float s[2];          // squared range
+    int pix[2];          // pixel (final when ok, the estimate otherwise)
+    bool ok[2];          // inside the range window and certain
+    bool park[2];        // inside the range window, not certain: resolve with nsc_point_exact
+};
+
+__device__ __forceinline__ nsc_f32x2 nsc_pk_fma(nsc_f32x2 a, nsc_f32x2 b, float c)
+{
+    return __builtin_elementwise_fma(a, b, nsc_f32x2{c, c});
+}
+
+__device__ __forceinline__ NscLeanPair nsc_point_lean_pair(float xa, float ya, float za, float xb, float yb, float zb,
+                                                           const NscBinParams &bp)
+{
+    NscLeanPair r;
+    // (x^2, y^2) of one point is one packed multiply on the register pair the load left them in; the empty asm
+    // statements keep the SLP vectoriser from pairing the remaining scalar operations ACROSS the two points, which
+    // costs a register move per operand
+    float sxy0 = xa * xa + ya * ya, sxy1 = xb * xb + yb * yb;
+    asm("" : "+v"(sxy0));
+    asm("" : "+v"(sxy1));
+    float zz0 = za * za, zz1 = zb * zb;
+    asm("" : "+v"(zz0));
+    asm("" : "+v"(zz1));
+    r.s[0] = sxy0 + zz0;
+    asm("" : "+v"(r.s[0]));
+    r.s[1] = sxy1 + zz1;
+    const bool keep0 = r.s[0] >= bp.s_lo && r.s[0] <= bp.s_hi, keep1 = r.s[1] >= bp.s_lo && r.s[1] <= bp.s_hi;
+    // column
+    const nsc_f32x2 mn = {nsc_absmin(xa, ya), nsc_absmin(xb, yb)};
+    const nsc_f32x2 rc = {nsc_rcp_approx(nsc_absmax(xa, ya)), nsc_rcp_approx(nsc_absmax(xb, yb))};
+    const nsc_f32x2 t = mn * rc;
+    const nsc_f32x2 w = t * t;
+    nsc_f32x2 p = nsc_pk_fma(nsc_f32x2{-2.3230952024e-01f, -2.3230952024e-01f}, w, 1.2526550293e+00f);
+    p = nsc_pk_fma(p, w, -3.2035398483e+00f);
+    p = nsc_pk_fma(p, w, 5.5245718956e+00f);
+    p = nsc_pk_fma(p, w, -7.9690575600e+00f);
+    p = nsc_pk_fma(p, w, 1.1428540230e+01f);
+    p = nsc_pk_fma(p, w, -1.9096603394e+01f);
+    p = nsc_pk_fma(p, w, 5.7295742035e+01f);
+    const nsc_f32x2 q = p * t;
+    const nsc_f32x2 gc = nsc_f32x2{nsc_fractf(q.x), nsc_fractf(q.y)} - nsc_f32x2{0.5f, 0.5f};
+    const float cthr = (0.5f - NSC_LEAN_GUARD) - bp.az_delta;
+    const bool cok0 = fabsf(gc.x) < cthr, cok1 = fabsf(gc.y) < cthr;
+    // nsc_unfold_octant on both halves
+    const nsc_f32x2 c = nsc_f32x2{45.0f, 45.0f} - q;
+    const nsc_f32x2 b = nsc_f32x2{45.0f, 45.0f} + nsc_f32x2{__builtin_copysignf(c.x, nsc_absdiff(xa, ya)),
+                                                           __builtin_copysignf(c.y, nsc_absdiff(xb, yb))};
+    const nsc_f32x2 a2 = nsc_f32x2{90.0f, 90.0f} - nsc_f32x2{__builtin_copysignf(b.x, xa), __builtin_copysignf(b.y, xb)};
+    const nsc_f32x2 colf = nsc_f32x2{180.0f, 180.0f} + nsc_f32x2{__builtin_copysignf(a2.x, ya), __builtin_copysignf(a2.y, yb)};
+    // row
+    const nsc_f32x2 e = {nsc_clampf(za * nsc_rsq_approx(sxy0), -0.62f, 0.62f), nsc_clampf(zb * nsc_rsq_approx(sxy1), -0.62f, 0.62f)};
+    const nsc_f32x2 v = e * e;
+    nsc_f32x2 a = nsc_pk_fma(nsc_f32x2{-3.6013321370e-02f, -3.6013321370e-02f}, v, 8.9950942561e-02f);
+    a = nsc_pk_fma(a, v, -1.3851101441e-01f);
+    a = nsc_pk_fma(a, v, 1.9954741257e-01f);
+    a = nsc_pk_fma(a, v, -3.3331274679e-01f);
+    a = nsc_pk_fma(a, v, 9.9999973037e-01f);
+    a = a * e;
+    const nsc_f32x2 uu = __builtin_elementwise_fma(a, nsc_f32x2{bp.el_u_scale, bp.el_u_scale},
+                                                   nsc_f32x2{bp.el_u_bias, bp.el_u_bias});
+    const float uhi = (float)bp.E - 0.5f;
+    const nsc_f32x2 u = {nsc_clampf(uu.x, -0.5f, uhi), nsc_clampf(uu.y, -0.5f, uhi)};
+    const nsc_f32x2 gr = nsc_f32x2{nsc_fractf(u.x), nsc_fractf(u.y)} - nsc_f32x2{0.5f, 0.5f};
+    const float rthr = (0.5f - NSC_LEAN_GUARD) - bp.el_delta;
+    const bool rok0 = fabsf(gr.x) < rthr, rok1 = fabsf(gr.y) < rthr;
+    r.pix[0] = nsc_mul24((int)u.x, NSC_A) + (int)colf.x;
+    r.pix[1] = nsc_mul24((int)u.y, NSC_A) + (int)colf.y;
+    const bool c0 = cok0 && rok0, c1 = cok1 && rok1;
+    r.ok[0] = keep0 && c0;
+    r.ok[1] = keep1 && c1;
+    r.park[0] = keep0 && !c0;
+    r.park[1] = keep1 && !c1;
+    return r;
+}
+#endif
 
 // 0 = dropped, 1 = (pix, s) certain, 2 = uncertain (host-side checks)
 NSC_HD int nsc_point_lean(float x, float y, float z, const NscBinParams &bp, int &pix, float &s)

@@ -149,16 +149,12 @@ __device__ __forceinline__ void scatter_range(const float *__restrict__ pts, lon
 // interpolate one row in LDS (one wavefront)                    range_image.py:33-64
 // ---------------------------------------------------------------------------------------------
 // method: 0 = count the valid pixels only, 1 = circular linear (np.interp, :52-64), 2 = circular nearest (:66-75)
-__device__ __forceinline__ int interp_row(float *row, int lane, int method)
+// v[j] = row[lane + 64 j] (0 beyond column 359), already in registers
+__device__ __forceinline__ int interp_row_v(float *row, int lane, int method, const float (&v)[6])
 {
-    float v[6];
     unsigned long long m[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int c = lane + 64 * j;
-        v[j] = (c < A) ? row[c] : 0.0f;
-        m[j] = __ballot(v[j] > 0.0f);                            // :35 valid_mask = row > 0
-    }
+    for (int j = 0; j < 6; ++j) m[j] = __ballot(v[j] > 0.0f);    // :35 valid_mask = row > 0
     int nv = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) nv += __popcll(m[j]);
@@ -216,6 +212,17 @@ __device__ __forceinline__ int interp_row(float *row, int lane, int method)
         }
     }
     return nv;
+}
+
+__device__ __forceinline__ int interp_row(float *row, int lane, int method)
+{
+    float v[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = (c < A) ? row[c] : 0.0f;
+    }
+    return interp_row_v(row, lane, method, v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,102 +295,150 @@ __device__ __forceinline__ void fft_load_row(const float *x, int lane, f32x2 (&i
         in[r] = (lane < 45) ? *reinterpret_cast<const f32x2 *>(&x[2 * (lane + 45 * r)]) : f32x2{0.f, 0.f};
 }
 
-__device__ __forceinline__ void fft_row_regs(const f32x2 (&in)[4], double2 *buf, const double2 *tw, float *mags,
-                                             int lane)
+// NR rows at once, each in its own scratch buffer: the same four stages, with the NR independent butterflies of a lane
+// interleaved by the compiler (one row alone is a chain of LDS round trips with nothing to overlap them).  The
+// inter-stage twiddles depend on the lane only and are read once for all rows.  Returns |X[k]| of row p for
+// k = lane + 64 jj in mg[p][jj] (0 beyond k = 180); every read of buf precedes the return in program order, so the
+// caller may store the magnitudes over the scratch.
+template <int NR>
+__device__ __forceinline__ void fft_rows(const f32x2 (*in)[4], double2 *const (&buf)[NR], const double2 *tw,
+                                         float (&mg)[NR][3], int lane)
 {
     {   // stage 1: R = 4, Ns = 1, 45 butterflies, input = the float32 image row (held in registers)
-        double re[4], im[4];
         if (lane < 45) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { re[r] = (double)in[r].x; im[r] = (double)in[r].y; }
-            dft4(re, im);
+            for (int p = 0; p < NR; ++p) {
+                double re[4], im[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[4 * lane + q] = o; }
+                for (int r = 0; r < 4; ++r) { re[r] = (double)in[p][r].x; im[r] = (double)in[p][r].y; }
+                dft4(re, im);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[p][4 * lane + q] = o; }
+            }
         }
     }
     wave_sync();
     {   // stage 2: R = 5, Ns = 4, 36 butterflies, W = W360^(18 r k)
-        double re[5], im[5];
+        double re[NR][5], im[NR][5];
         const int k = lane & 3;
         if (lane < 36) {
             double2 w[5];
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const double2 v = buf[lane + 36 * r];
-                re[r] = v.x; im[r] = v.y;
-                if (r) w[r] = tw[18 * r * k];
-            }
+            for (int r = 1; r < 5; ++r) w[r] = tw[18 * r * k];
 #pragma unroll
-            for (int r = 1; r < 5; ++r) twmul(re[r], im[r], w[r]);
-            dft5(re, im);
+            for (int p = 0; p < NR; ++p)
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const double2 v = buf[p][lane + 36 * r];
+                    re[p][r] = v.x; im[p][r] = v.y;
+                }
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+#pragma unroll
+                for (int r = 1; r < 5; ++r) twmul(re[p][r], im[p][r], w[r]);
+                dft5(re[p], im[p]);
+            }
         }
         wave_sync();
         if (lane < 36) {
             const int j0 = (lane >> 2) * 20 + k;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[j0 + 4 * q] = o; }
+            for (int p = 0; p < NR; ++p)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) { double2 o; o.x = re[p][q]; o.y = im[p][q]; buf[p][j0 + 4 * q] = o; }
         }
     }
     wave_sync();
     {   // stage 3: R = 3, Ns = 20, 60 butterflies, W = W360^(6 r k)
-        double re[3], im[3];
+        double re[NR][3], im[NR][3];
         const int k = lane % 20;
         if (lane < 60) {
-            double2 w[3];
+            const double2 w1 = tw[6 * k], w2 = tw[12 * k];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double2 v = buf[lane + 60 * r];
-                re[r] = v.x; im[r] = v.y;
-                if (r) w[r] = tw[6 * r * k];
+            for (int p = 0; p < NR; ++p)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double2 v = buf[p][lane + 60 * r];
+                    re[p][r] = v.x; im[p][r] = v.y;
+                }
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                twmul(re[p][1], im[p][1], w1);
+                twmul(re[p][2], im[p][2], w2);
+                dft3(re[p], im[p]);
             }
-            twmul(re[1], im[1], w[1]);
-            twmul(re[2], im[2], w[2]);
-            dft3(re, im);
         }
         wave_sync();
         if (lane < 60) {
             const int j0 = (lane / 20) * 60 + k;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[j0 + 20 * q] = o; }
+            for (int p = 0; p < NR; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { double2 o; o.x = re[p][q]; o.y = im[p][q]; buf[p][j0 + 20 * q] = o; }
         }
     }
     wave_sync();
     {   // stage 4: R = 3, Ns = 60, 60 butterflies, W = W360^(2 r k), k = j
-        double re[3], im[3];
+        double re[NR][3], im[NR][3];
         if (lane < 60) {
-            double2 w[3];
+            const double2 w1 = tw[2 * lane], w2 = tw[4 * lane];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double2 v = buf[lane + 60 * r];
-                re[r] = v.x; im[r] = v.y;
-                if (r) w[r] = tw[2 * r * lane];
+            for (int p = 0; p < NR; ++p)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double2 v = buf[p][lane + 60 * r];
+                    re[p][r] = v.x; im[p][r] = v.y;
+                }
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                twmul(re[p][1], im[p][1], w1);
+                twmul(re[p][2], im[p][2], w2);
+                dft3(re[p], im[p]);
             }
-            twmul(re[1], im[1], w[1]);
-            twmul(re[2], im[2], w[2]);
-            dft3(re, im);
         }
         wave_sync();
         if (lane < 60) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[lane + 60 * q] = o; }
+            for (int p = 0; p < NR; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { double2 o; o.x = re[p][q]; o.y = im[p][q]; buf[p][lane + 60 * q] = o; }
         }
     }
     wave_sync();
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {                   // unpack the real spectrum, |X[k]| -> float32
         const int k = lane + 64 * jj;
+#pragma unroll
+        for (int p = 0; p < NR; ++p) mg[p][jj] = 0.0f;
         if (k <= NH) {
-            const double2 zk = buf[k == NH ? 0 : k];
-            const double2 zn = buf[(k == 0 || k == NH) ? 0 : NH - k];
             const double2 w = tw[k];
-            const double sp = zk.x + zn.x, sm = zk.x - zn.x;   // a+c, a-c
-            const double tp = zk.y + zn.y, tm = zk.y - zn.y;   // b+d, b-d
-            const double xr = 0.5 * (sp + tp * w.x - sm * w.y);
-            const double xi = 0.5 * (tm - sm * w.x - tp * w.y);
-            // :183 (the x sqrt(360) of :186 undoes 'ortho').  |X|^2 in float64, one float32 rounding,
-            // then a correctly rounded float32 sqrt: within 1 ULP of (float)sqrt(double)
-            mags[k] = sqrtf((float)(xr * xr + xi * xi));
+#pragma unroll
+            for (int p = 0; p < NR; ++p) {
+                const double2 zk = buf[p][k == NH ? 0 : k];
+                const double2 zn = buf[p][(k == 0 || k == NH) ? 0 : NH - k];
+                const double sp = zk.x + zn.x, sm = zk.x - zn.x;   // a+c, a-c
+                const double tp = zk.y + zn.y, tm = zk.y - zn.y;   // b+d, b-d
+                const double xr = 0.5 * (sp + tp * w.x - sm * w.y);
+                const double xi = 0.5 * (tm - sm * w.x - tp * w.y);
+                // :183 (the x sqrt(360) of :186 undoes 'ortho').  |X|^2 in float64, one float32 rounding,
+                // then a correctly rounded float32 sqrt: within 1 ULP of (float)sqrt(double)
+                mg[p][jj] = sqrtf((float)(xr * xr + xi * xi));
+            }
         }
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ void fft_row_regs(const f32x2 (&in)[4], double2 *buf, const double2 *tw, float *mags,
+                                             int lane)
+{
+    float mg[1][3];
+    double2 *const bufs[1] = {buf};
+    fft_rows<1>(&in, bufs, tw, mg, lane);
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int k = lane + 64 * jj;
+        if (k <= NH) mags[k] = mg[0][jj];
     }
     wave_sync();
 }
@@ -757,7 +812,24 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
 #endif
 }
 
-__device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d, const int *__restrict__ lut,
+// The tables the finish needs from global memory, one element per thread; their latency lands under the square roots
+// (loading them before the stream and carrying them through it measured the same).
+struct FinishTables {
+    double2 twv;                  // g_tw360[tid]
+    int lut_cur, lut_prev;        // lut[tid], lut[tid - 1]
+};
+
+__device__ __forceinline__ FinishTables load_finish_tables(const int *__restrict__ lut, int tid)
+{
+    FinishTables t;
+    t.twv = double2{0.0, 0.0};
+    t.lut_cur = t.lut_prev = -1;
+    if (tid < TW_N) t.twv = g_tw360[tid];
+    if (tid < F) { t.lut_cur = lut[tid]; t.lut_prev = tid ? lut[tid - 1] : -1; }
+    return t;
+}
+
+__device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d, const FinishTables &ft,
                                             float *__restrict__ out_desc, float *__restrict__ out_raw,
                                             float *__restrict__ out_interp)
 {
@@ -772,32 +844,40 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
     int *rowflag = reinterpret_cast<int *>(lds + lp.misc + MAXR * 8);
     int *rowsrc = rowflag + 16;
 
-    // the twiddle table replaces the (drained) queue; its global loads land under the sqrt / interpolation below
-    double2 twv = {0.0, 0.0};
-    if (tid < TW_N) twv = g_tw360[tid];
-    // histogram segments (see setup_tables): bin b owns the frequencies [seg[b], seg[B + b]).  One round of loads, no
-    // dependent search: thread k sees where the monotone LUT steps at frequency k and writes the bins that start there.
-    int lut_prev = -1, lut_cur = -1;
-    if (tid < F) { lut_cur = lut[tid]; lut_prev = tid ? lut[tid - 1] : -1; }
+    // the twiddle table replaces the (drained) queue.  Histogram segments (see setup_tables): bin b owns the
+    // frequencies [seg[b], seg[B + b]); no dependent search: thread k sees where the monotone LUT steps at frequency
+    // k and writes the bins that start there.
+    const double2 twv = ft.twv;
+    int lut_cur = ft.lut_cur;
+    const int lut_prev = ft.lut_prev;
 
     const int r0 = 4 * wave;                                      // this wave owns rows r0 .. r0 + 3
-    for (int r = r0; r < r0 + 4; ++r) {
-        float *row = img + r * A;
-        const unsigned *raw = reinterpret_cast<const unsigned *>(row);
-        float *graw = out_raw ? out_raw + r * A : nullptr;
+    {
+        float v[4][6];                                            // the four rows' square roots are independent
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int c = lane + 64 * j;
-            if (c < A) {
-                const unsigned v = raw[c];
-                const float rr = (v == NSC_EMPTY_BITS) ? 0.0f : sqrtf(__uint_as_float(v));   // :162,:214
-                row[c] = rr;
-                if (graw) graw[c] = rr;
+        for (int q = 0; q < 4; ++q) {
+            float *row = img + (r0 + q) * A;
+            const unsigned *raw = reinterpret_cast<const unsigned *>(row);
+            float *graw = out_raw ? out_raw + (r0 + q) * A : nullptr;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int c = lane + 64 * j;
+                v[q][j] = 0.0f;
+                if (c < A) {
+                    const unsigned b = raw[c];
+                    const float rr = (b == NSC_EMPTY_BITS) ? 0.0f : sqrtf(__uint_as_float(b));   // :162,:214
+                    v[q][j] = rr;
+                    row[c] = rr;
+                    if (graw) graw[c] = rr;
+                }
             }
         }
         wave_sync();
-        const int nv = interp_row(row, lane, d.interp);
-        if (lane == 0) rowflag[r] = (nv > 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nv = interp_row_v(img + (r0 + q) * A, lane, d.interp, v[q]);
+            if (lane == 0) rowflag[r0 + q] = (nv > 0);
+        }
     }
     if (tid < TW_N) tw[tid] = twv;
     if (tid < F) {
@@ -837,52 +917,65 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
     if (NSC_DEV_SKIP(d, 16)) return;
 
     // spectrum + histogram.  All four rows' stage-1 operands go to registers first; from then on the wave's 5 760
-    // image bytes are free: rows r0+1, r0+2 = FFT scratch (180 double2), row r0+3 = |X| (181 floats),
-    // row r0 = the four histograms (FAST_HSTRIDE floats apart).
+    // image bytes are two FFT scratch buffers (180 double2 each) and the rows run as two PAIRS, the two FFTs of a pair
+    // interleaved instruction by instruction.  The magnitudes of a row land on its own scratch once the unpack has
+    // read it, the histogram value of bin `lane` of each of the four rows stays in a register until the normalisation.
     f32x2 in[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) fft_load_row(img + (r0 + q) * A, lane, in[q]);
     wave_sync();
-    double2 *fftbuf = reinterpret_cast<double2 *>(img + (r0 + 1) * A);
-    float *mags = img + (r0 + 3) * A;
-    float *hist0 = img + r0 * A;
+    double2 *const bufs[2] = {reinterpret_cast<double2 *>(img + r0 * A), reinterpret_cast<double2 *>(img + (r0 + 2) * A)};
+    float h[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    double part = 0.0;
+    const int k0 = lane < B ? seg[lane] : 0, k1 = lane < B ? seg[B + lane] : 0;     // B <= 64: one bin per lane
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (!NSC_DEV_SKIP(d, 4)) fft_row_regs(in[q], fftbuf, tw, mags, lane);
-        double part = 0.0;
-        if (!NSC_DEV_SKIP(d, 8))
-        for (int b = lane; b < B; b += 64) {
-            float h = 0.0f;
-            const int k1 = seg[B + b];
-            for (int k = seg[b]; k < k1; k += 8) {               // scatter_add_, ascending k (:152-155)
-                float v[8];
+    for (int pr = 0; pr < 2; ++pr) {
+        float mg[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (!NSC_DEV_SKIP(d, 4)) fft_rows<2>(in + 2 * pr, bufs, tw, mg, lane);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (k + u < k1) ? mags[k + u] : 0.0f;
+        for (int p = 0; p < 2; ++p) {
+            float *mags = reinterpret_cast<float *>(bufs[p]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) h += v[u];            // h + 0.0f == h: order and rounding unchanged
+            for (int jj = 0; jj < 3; ++jj) {
+                const int k = lane + 64 * jj;
+                if (k <= NH) mags[k] = mg[p][jj];
             }
-            hist0[FAST_HSTRIDE * q + b] = h;
-            part += (double)h;
         }
-        part = wave_sum(part);
-        if (lane == 0) rowsum[r0 + q] = part;
-        wave_sync();                                              // mags / scratch are rewritten by the next row
+        wave_sync();
+        if (!NSC_DEV_SKIP(d, 8)) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float *mags = reinterpret_cast<const float *>(bufs[p]);
+                float acc = 0.0f;
+                for (int k = k0; k < k1; k += 8) {               // scatter_add_, ascending k (:152-155)
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = (k + u < k1) ? mags[k + u] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += v[u];      // acc + 0.0f == acc: order and rounding unchanged
+                }
+                h[2 * pr + p] = acc;
+                part += (double)acc;
+            }
+        }
+        wave_sync();                                              // the magnitudes are overwritten by the next pair
     }
+    part = wave_sum(part);
+    if (lane == 0) rowsum[wave] = part;
     __syncthreads();
 
-    double tot = 0.0;
-    for (int r = 0; r < E; ++r) tot += rowsum[r];
+    const double tot = (rowsum[0] + rowsum[1]) + (rowsum[2] + rowsum[3]);
     const float s = (float)tot;                                   // :197
-    const int D = E * B;
-    if (s > d.eps) {
-        const float den = s + d.eps;                              // :199
-        for (int i = tid; i < D; i += NT) {
-            const int r = i / B, b = i - r * B;
-            out_desc[i] = img[(r & ~3) * A + FAST_HSTRIDE * (r & 3) + b] / den;
+    if (lane < B) {
+        if (s > d.eps) {
+            const float den = s + d.eps;                          // :199
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out_desc[(r0 + q) * B + lane] = h[q] / den;
+        } else {
+            const float u = 1.0f / (float)(E * B);                // :202
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out_desc[(r0 + q) * B + lane] = u;
         }
-    } else {
-        const float u = 1.0f / (float)D;                          // :202
-        for (int i = tid; i < D; i += NT) out_desc[i] = u;
     }
 }
 
@@ -907,6 +1000,9 @@ __global__ __launch_bounds__(256, 4) void encode_fast_kernel(
     __syncthreads();
     const long long p0 = off[c];
     const int n = (int)(off[c + 1] - p0);                           // < 2^27 (host check)
+#ifdef NSC_DEV_TUNING
+    if (NSC_DEV_SKIP(d, 32)) __builtin_amdgcn_s_setprio(3);
+#endif
 #ifdef NSC_DEV_TUNING
     if (d.dev_stagger > 0) {          // workgroups b, b + 256, b + 512, b + 768 are expected to share a CU
         const int units = ((blockIdx.x >> 8) & 3) * d.dev_stagger;
@@ -940,7 +1036,7 @@ __global__ __launch_bounds__(256, 4) void encode_fast_kernel(
         return;
     }
     const long long D = 16LL * d.B;
-    finish_fast(lds, d, lut, out_desc + c * D, out_raw ? out_raw + (long long)c * 16 * A : nullptr,
+    finish_fast(lds, d, load_finish_tables(lut, tid), out_desc + c * D, out_raw ? out_raw + (long long)c * 16 * A : nullptr,
                 out_interp ? out_interp + (long long)c * 16 * A : nullptr);
 }
 

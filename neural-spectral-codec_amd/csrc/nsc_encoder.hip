@@ -318,34 +318,34 @@ __device__ __forceinline__ void fft_rows(const f32x2 (*in)[4], double2 *const (&
         }
     }
     wave_sync();
-    {   // stage 2: R = 5, Ns = 4, 36 butterflies, W = W360^(18 r k)
-        double re[NR][5], im[NR][5];
+    {   // stage 2: R = 5, Ns = 4, 36 butterflies, W = W360^(18 r k).  One row after the other (each in place in its
+        // own buffer): two radix-5 butterflies in flight are 40 more live registers than the kernel's budget beside
+        // the GNN waves allows, and the only stage where that is so.
         const int k = lane & 3;
+        const int j0 = (lane >> 2) * 20 + k;
+        double2 w[5];
         if (lane < 36) {
-            double2 w[5];
 #pragma unroll
             for (int r = 1; r < 5; ++r) w[r] = tw[18 * r * k];
+        }
 #pragma unroll
-            for (int p = 0; p < NR; ++p)
+        for (int p = 0; p < NR; ++p) {
+            double re[5], im[5];
+            if (lane < 36) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     const double2 v = buf[p][lane + 36 * r];
-                    re[p][r] = v.x; im[p][r] = v.y;
+                    re[r] = v.x; im[r] = v.y;
                 }
 #pragma unroll
-            for (int p = 0; p < NR; ++p) {
-#pragma unroll
-                for (int r = 1; r < 5; ++r) twmul(re[p][r], im[p][r], w[r]);
-                dft5(re[p], im[p]);
+                for (int r = 1; r < 5; ++r) twmul(re[r], im[r], w[r]);
+                dft5(re, im);
             }
-        }
-        wave_sync();
-        if (lane < 36) {
-            const int j0 = (lane >> 2) * 20 + k;
+            wave_sync();
+            if (lane < 36) {
 #pragma unroll
-            for (int p = 0; p < NR; ++p)
-#pragma unroll
-                for (int q = 0; q < 5; ++q) { double2 o; o.x = re[p][q]; o.y = im[p][q]; buf[p][j0 + 4 * q] = o; }
+                for (int q = 0; q < 5; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[p][j0 + 4 * q] = o; }
+            }
         }
     }
     wave_sync();
@@ -425,6 +425,7 @@ __device__ __forceinline__ void fft_rows(const f32x2 (*in)[4], double2 *const (&
                 mg[p][jj] = sqrtf((float)(xr * xr + xi * xi));
             }
         }
+        if (NR > 1) wave_sync();            // keeps the three passes' operands from being live at once (register budget)
     }
     wave_sync();
 }
@@ -980,7 +981,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
 }
 
 template <int U, bool PAIR = true>
-__global__ __launch_bounds__(256, 4) void encode_fast_kernel(
+__global__ __launch_bounds__(256, 5) void encode_fast_kernel(
     const float *__restrict__ pts, const long long *__restrict__ off, EncDev d, const int *__restrict__ lut,
     float *__restrict__ out_desc, float *__restrict__ out_raw, float *__restrict__ out_interp)
 {
@@ -1311,6 +1312,12 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
                                    out_desc, out_raw, out_interp);
             else if (variant == -3)
                 hipLaunchKernelGGL(encode_fast_kernel<12>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
+                                   out_desc, out_raw, out_interp);
+            else if (variant == -5)
+                hipLaunchKernelGGL(encode_fast_kernel<2>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
+                                   out_desc, out_raw, out_interp);
+            else if (variant == -6)
+                hipLaunchKernelGGL(encode_fast_kernel<6>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
                                    out_desc, out_raw, out_interp);
             else if (variant == -4)
                 hipLaunchKernelGGL((encode_fast_kernel<8, false>), dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d,

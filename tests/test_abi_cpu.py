@@ -101,3 +101,35 @@ def test_binning_margins_host(tmp_path, bias):
     out = subprocess.check_output([exe, "4000000", "23", "-24.8", "2.0", "16", "1", "1", "0"]).decode().split()
     n, azu, elu, azw, elw = map(int, out[:5])
     assert azw == 0 and elw == 0 and azu < 1e-3 * n, out
+
+
+def test_coresident_register_budget(lib, tmp_path):
+    """The two-stream step depends on occupancy arithmetic the compiler can silently break: four resident encoder
+    waves per SIMD lane at <= 96 VGPRs leave 128 of the 512 registers, room for two waves of the LDS-free GNN kernels
+    (<= 64 VGPRs each).  At 114 encoder VGPRs (seen once, after a finish-stage change) the GNN waves no longer fit
+    beside the encoder and the step slowed by 3 % with a FASTER encoder.  Read the budgets from the code objects."""
+    import shutil
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("llvm binutils of the ROCm image not found")
+    so = shutil.copy(os.path.join(CSRC, "libnsc_hip.so"), tmp_path / "libnsc_hip.so")
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    kernels = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(tmp_path / f)], check=True,
+                               capture_output=True, text=True).stdout
+        for blk in notes.split(".agpr_count")[1:]:          # one metadata map per kernel, keys in alphabetical order
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if name and vg and sc:
+                kernels[name.group(1)] = (int(vg.group(1)), int(sc.group(1)))
+    enc = [v for k, v in kernels.items() if "encode_fast_kernelILi8ELb1" in k]
+    assert len(enc) == 1, sorted(kernels)
+    assert enc[0][0] <= 96 and enc[0][1] == 0, f"encode_fast_kernel<8>: {enc[0][0]} VGPRs, {enc[0][1]} B scratch"
+    co = {k: v for k, v in kernels.items() if "gemm_nt_direct_kernel" in k or "gat_aggregate_kernelILi1ELi4ELb0" in k}
+    assert len(co) >= 4, sorted(kernels)
+    for k, (vg, sc) in co.items():
+        assert vg <= 64 and sc == 0, f"{k}: {vg} VGPRs, {sc} B scratch"

@@ -113,7 +113,7 @@ def cpu_baseline(pts_dev, off_dev, model, n_sample):
     }, desc
 
 
-EV_EVERY = 4
+EV_EVERY = 1
 CALIB_STEPS = 30
 GAT_FLOP_PER_NODE = 2.0 * (800 * 256 + 3 * 256 * 256 + 256 * 800)      # 5.51 GFLOP at N = 4 541
 MFMA_F32_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md: f32-input MFMA
@@ -306,8 +306,8 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             # the encoder kernel is bracketed by HIP events on the stream it is launched on -> live per-launch
-            # duration for the roofline object.  Every EV_EVERY-th launch is bracketed: a timing-event pair
-            # costs ~7 us of idle between two back-to-back encoder launches of the pipelined path.
+            # duration for the roofline object.  Every launch is bracketed (EV_EVERY = 1): measured in round 2, the step
+            # time is the same with every launch, every 4th or every 50th launch timed.
             desc_all, emb = path.step((pts, off), encoder_events=ev[k] if k % EV_EVERY == 0 else None, inputs_ready=True)
         t_issue = time.perf_counter() - t0                  # host side only: all K steps enqueued
         sync()

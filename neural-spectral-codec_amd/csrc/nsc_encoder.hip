@@ -1002,6 +1002,10 @@ __global__ __launch_bounds__(256, 5) void encode_fast_kernel(
     const long long p0 = off[c];
     const int n = (int)(off[c + 1] - p0);                           // < 2^27 (host check)
 #ifdef NSC_DEV_TUNING
+    const unsigned long long dev_t0 = wall_clock64();
+    unsigned long long dev_t1 = 0;
+#endif
+#ifdef NSC_DEV_TUNING
     if (NSC_DEV_SKIP(d, 32)) __builtin_amdgcn_s_setprio(3);
 #endif
 #ifdef NSC_DEV_TUNING
@@ -1032,11 +1036,26 @@ __global__ __launch_bounds__(256, 5) void encode_fast_kernel(
         }
     }
     __syncthreads();
+#ifdef NSC_DEV_TUNING
+    dev_t1 = wall_clock64();
+#endif
     if (NSC_DEV_SKIP(d, 1)) {
         if (tid == 0) out_desc[(long long)c * 16 * d.B] = __uint_as_float(img[0]);
         return;
     }
     const long long D = 16LL * d.B;
+#ifdef NSC_DEV_TUNING
+    if (NSC_DEV_SKIP(d, 512)) {         // per-workgroup timeline probe (tools/wg_timeline.py): 100 MHz wall clock
+        finish_fast(lds, d, load_finish_tables(lut, tid), out_desc + c * D, nullptr, nullptr);
+        __syncthreads();
+        if (tid == 0) {
+            out_desc[c * D + 0] = __uint_as_float((unsigned)dev_t0);
+            out_desc[c * D + 1] = __uint_as_float((unsigned)dev_t1);
+            out_desc[c * D + 2] = __uint_as_float((unsigned)wall_clock64());
+        }
+        return;
+    }
+#endif
     finish_fast(lds, d, load_finish_tables(lut, tid), out_desc + c * D, out_raw ? out_raw + (long long)c * 16 * A : nullptr,
                 out_interp ? out_interp + (long long)c * 16 * A : nullptr);
 }

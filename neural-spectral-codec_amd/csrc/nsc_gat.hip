@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
     f32x4 acc[ACC];
 #pragma unroll
     for (int h = 0; h < ACC; ++h) acc[h] = zero;
+    // A wave whose 16 columns all lie beyond N only helps with the staging (the fifth column block of the lin GEMMs
+    // carries just the two attention columns): it skips the operand reads and the MFMAs.
+    const bool active = n0 + wave * 16 < N;
 
     // Register ring of PD chunks: every global load of the next PD chunks is in flight while the current
     // chunk's MFMAs run, so one L2 round trip is exposed per kernel instead of one per chunk (these GEMMs
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
                 const int kleft = K - ch * BK;
 #pragma unroll
                 for (int d = 0; d < BK / 16; ++d) {
-                    if (16 * d < kleft) {
+                    if (16 * d < kleft && active) {
                         const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
                         f32x4 av[ACC];
 #pragma unroll
@@ -382,6 +385,9 @@ __global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__rest
     const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int m0 = (int)(tile / gridDim.x) * BM, n0 = (int)(tile % gridDim.x) * 64;
     const int cb = n0 + wave * 16 + r;
+    // A wave whose 16 columns all lie beyond N has nothing to compute (no barriers in this kernel): in the lin GEMMs the
+    // fifth column block carries only the two attention columns, three of its four waves leave here.
+    if (n0 + wave * 16 >= N) return;
 
     // Load mapping: lane L fetches 16 bytes of row L >> 2 at k offset 4 (L & 3), so 4 neighbouring lanes read
     // 64 contiguous bytes and a 16-lane quad touches 4 cache lines.  (Loading in the MFMA operand layout

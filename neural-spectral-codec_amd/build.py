@@ -31,8 +31,26 @@ def _deps():
             + glob.glob(os.path.join(root, "include", "*.h")))
 
 
+FLAGS_FILE = LIB + ".flags"        # the flags the library in place was built with (a development build must not
+                                   # pass for the product build just because it is newer than the sources)
+
+
+def _flags():
+    flags = list(HIPCC_FLAGS)
+    if os.environ.get("NSC_DEV_BUILD") == "1":       # enables the NSC_TUNE_* development knobs
+        flags.append("-DNSC_DEV_TUNING")
+    for d in os.environ.get("NSC_DEV_DEFINES", "").split():      # development A/B builds
+        flags.append("-D" + d)
+    return flags
+
+
 def is_stale():
     if not os.path.exists(LIB):
+        return True
+    try:
+        if open(FLAGS_FILE).read() != " ".join(_flags()):
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(f) > t for f in _deps())
@@ -43,15 +61,13 @@ def build_hip(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    flags = list(HIPCC_FLAGS)
-    if os.environ.get("NSC_DEV_BUILD") == "1":       # enables the NSC_TUNE_* development knobs
-        flags.append("-DNSC_DEV_TUNING")
-    for d in os.environ.get("NSC_DEV_DEFINES", "").split():      # development A/B builds
-        flags.append("-D" + d)
+    flags = _flags()
     cmd = [hipcc] + flags + ["-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(FLAGS_FILE, "w") as f:
+        f.write(" ".join(flags))
     return LIB
 
 

@@ -852,6 +852,13 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
     int lut_cur = ft.lut_cur;
     const int lut_prev = ft.lut_prev;
 
+#ifdef NSC_DEV_TUNING
+    unsigned long long st[7];
+#define NSC_STAMP(i) st[i] = wall_clock64()
+#else
+#define NSC_STAMP(i)
+#endif
+    NSC_STAMP(0);
     const int r0 = 4 * wave;                                      // this wave owns rows r0 .. r0 + 3
     {
         float v[4][6];                                            // the four rows' square roots are independent
@@ -880,6 +887,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
             if (lane == 0) rowflag[r0 + q] = (nv > 0);
         }
     }
+    NSC_STAMP(1);
     if (tid < TW_N) tw[tid] = twv;
     if (tid < F) {
         lut_cur = min(lut_cur, B - 1);
@@ -888,6 +896,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
             for (int b = lut_cur; b < B; ++b) { seg[B + b] = F; if (b > lut_cur) seg[b] = F; }
     }
     __syncthreads();
+    NSC_STAMP(2);
     if (d.interp) {                                               // range_image.py:77-87
         unsigned ne = 0u;
         for (int r = 0; r < E; ++r) ne |= (unsigned)(rowflag[r] != 0) << r;
@@ -921,6 +930,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
     // image bytes are two FFT scratch buffers (180 double2 each) and the rows run as two PAIRS, the two FFTs of a pair
     // interleaved instruction by instruction.  The magnitudes of a row land on its own scratch once the unpack has
     // read it, the histogram value of bin `lane` of each of the four rows stays in a register until the normalisation.
+    NSC_STAMP(3);
     f32x2 in[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) fft_load_row(img + (r0 + q) * A, lane, in[q]);
@@ -961,9 +971,11 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
         }
         wave_sync();                                              // the magnitudes are overwritten by the next pair
     }
+    NSC_STAMP(4);
     part = wave_sum(part);
     if (lane == 0) rowsum[wave] = part;
     __syncthreads();
+    NSC_STAMP(5);
 
     const double tot = (rowsum[0] + rowsum[1]) + (rowsum[2] + rowsum[3]);
     const float s = (float)tot;                                   // :197
@@ -978,6 +990,15 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
             for (int q = 0; q < 4; ++q) out_desc[(r0 + q) * B + lane] = u;
         }
     }
+#ifdef NSC_DEV_TUNING
+    if (NSC_DEV_SKIP(d, 512)) {
+        NSC_STAMP(6);
+        __syncthreads();
+        if (tid == 0)
+            for (int i = 0; i < 7; ++i) out_desc[3 + i] = __uint_as_float((unsigned)st[i]);
+    }
+#endif
+#undef NSC_STAMP
 }
 
 template <int U, bool PAIR = true>

@@ -181,6 +181,9 @@ struct GemmEpi {
     const float *resid;                             // (M, ldr) added last, nullable
     int ldr;
     float *aux0, *aux1;                             // columns n_main, n_main+1 (M each), nullable
+#ifdef NSC_DEV_TUNING
+    int dev;                                        // ablation bits (tools/r02_gat_ab2.sh): 1 no MFMAs, 2 no refills, 4 no LDS operand reads
+#endif
 };
 
 // EPI: 0 = plain store + aux columns (lin), 1 = bias + BatchNorm + ReLU (input_proj),
@@ -282,11 +285,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 #pragma unroll
                 for (int d = 0; d < BK / 16; ++d) {
                     if (16 * d < kleft && active) {
+#ifdef NSC_DEV_TUNING
+                        if (ep.dev & 4) {                  // no LDS operand reads: MFMAs on whatever the registers hold
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int h = 0; h < ACC; ++h)
+                                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[h][t], acc[h][3 - t], acc[h], 0, 0, 0);
+                            continue;
+                        }
+#endif
                         const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
                         f32x4 av[ACC];
 #pragma unroll
                         for (int h = 0; h < ACC; ++h)
                             av[h] = *reinterpret_cast<const f32x4 *>(&as[(16 * h + r) * LD + 16 * d + 4 * q]);
+#ifdef NSC_DEV_TUNING
+                        if (ep.dev & 1) {                  // no MFMAs: keep the operand reads alive
+#pragma unroll
+                            for (int h = 0; h < ACC; ++h) acc[h] += av[h] * bv;
+                            continue;
+                        }
+#endif
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -300,6 +320,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
                     for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[cur ^ 1][sa[i]]) = ra[ns][i];
 #pragma unroll
                     for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[cur ^ 1][sb[i]]) = rb[ns][i];
+#ifdef NSC_DEV_TUNING
+                    if (!(ep.dev & 2))
+#endif
                     if (ch + 1 + PD < nchunks) load_chunk(ch + 1 + PD, ra[ns], rb[ns]);
                 }
                 __syncthreads();
@@ -729,6 +752,11 @@ void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const
     pad = (unsigned)gat_tune_env("NSC_TUNE_GEMM_LDSPAD", 0);
 #endif
     const dim3 grid((N + 63) / 64, two ? (M + 31) / 32 : (M + 15) / 16);
+#ifdef NSC_DEV_TUNING
+    GemmEpi epd = ep;
+    epd.dev = gat_tune_env("NSC_TUNE_GEMM_ABL", 0);
+#define ep epd
+#endif
     if (coresident) {
         // one accumulator row block: 48 VGPRs.  Larger tiles (fewer B re-reads) were measured to disturb the
         // co-running encoder MORE (longer uninterrupted MFMA bursts), DESIGN.md section 7.
@@ -742,6 +770,9 @@ void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const
             hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), pad, st, A, lda, B, ldb, Bx, M, N, n_main,
                                K, C, ldc, ep);
     }
+#ifdef NSC_DEV_TUNING
+#undef ep
+#endif
 }
 
 }  // namespace

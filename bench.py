@@ -128,6 +128,8 @@ def measure_extras(enc, model, dev, n_local, scratch):
     from neural_spectral_codec_amd import synth
     from neural_spectral_codec_amd.keyframe import graph_manager as gm
     out = {}
+    gc.collect()
+    gc.disable()
     with torch.no_grad():
         inner = getattr(model, "gnn", model)
         was = inner.coresident
@@ -137,14 +139,17 @@ def measure_extras(enc, model, dev, n_local, scratch):
             g = gm.synthetic_chain_graph(n, device=dev, seed=1)
             for _ in range(5):
                 model(g)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(50):
-                model(g)
-            b.record()
-            torch.cuda.synchronize(dev)
-            us = a.elapsed_time(b) / 50 * 1e3
-            gat[n] = us
+            best = None
+            for _ in range(3):              # best of three rounds: a host hiccup (a late gc pass costs ~40 ms) in one
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # round must not
+                a.record()                                                                           # become the figure
+                for _ in range(50):
+                    model(g)
+                b.record()
+                torch.cuda.synchronize(dev)
+                us = a.elapsed_time(b) / 50 * 1e3
+                best = us if best is None else min(best, us)
+            gat[n] = best
         inner.coresident = was
         tf = GAT_FLOP_PER_NODE * 4541 / (gat[4541] * 1e-6) / 1e12
         out["roofline_gat"] = {
@@ -170,6 +175,7 @@ def measure_extras(enc, model, dev, n_local, scratch):
             orders[order] = a.elapsed_time(b) / 20
             del pts, off
         out["encoder_input_order_ms"] = orders
+    gc.enable()
     return out
 
 

@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
     // A wave whose 16 columns all lie beyond N only helps with the staging (the fifth column block of the lin GEMMs
     // carries just the two attention columns): it skips the operand reads and the MFMAs.
     const bool active = n0 + wave * 16 < N;
+#ifdef NSC_DEV_TUNING
+    f32x4 dev_c = {1.0f + (float)lane, 0.5f, 0.25f, 2.0f};
+    asm volatile("" : "+v"(dev_c));
+#endif
 
     // Register ring of PD chunks: every global load of the next PD chunks is in flight while the current
     // chunk's MFMAs run, so one L2 round trip is exposed per kernel instead of one per chunk (these GEMMs
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
                             for (int t = 0; t < 4; ++t)
 #pragma unroll
                                 for (int h = 0; h < ACC; ++h)
-                                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[h][t], acc[h][3 - t], acc[h], 0, 0, 0);
+                                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(dev_c[t], dev_c[3 - t], acc[h], 0, 0, 0);
                             continue;
                         }
 #endif

@@ -196,20 +196,27 @@ struct GemmEpi {
 // The epilogue goes back through LDS so that every output row leaves as 256 contiguous bytes (float4 per lane);
 // the residual is read the same way.  (Measured and dropped in round 2: two MFMA chains per tile, operand fetches
 // one block ahead of the MFMAs, a two-slot ring -- 20 % slower on the 13-chunk input projection.)
-template <int ACC, int EPI>   // ACC accumulator row blocks of 16 rows per wave: workgroup tile (16*ACC) x 64
+// ACN = 2 (round 2): the four waves form a 2 x 2 grid and every wave owns ACC x 2 accumulator blocks (a 32 x 32 wave tile on a
+// 64 x 64 workgroup tile).  These GEMMs are LDS-bandwidth-bound (0.27 B of LDS traffic per FLOP with
+// 32 x 16 wave tiles, every wave reading the whole A tile); the square wave tile needs 0.18 B/FLOP.  The k order of every
+// output element is unchanged, so all variants (and the LDS-free set) stay bit-identical.
+template <int ACC, int EPI, int ACN = 1>   // wave tile (16*ACC) x (16*ACN); workgroup tile (16*ACC*WR) x 64
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ A, int lda,
                                                       const float *__restrict__ B, int ldb,
                                                       const float *__restrict__ Bx, int M, int N,
                                                       int n_main, int K, float *__restrict__ C, int ldc,
                                                       GemmEpi ep)
 {
-    constexpr int BM = 16 * ACC, BN = 64, BK = 64, LD = BK + 4;
-    constexpr int NA = BM * (BK / 4) / 256;    // float4 loads per thread for the A tile (1 or 2)
+    constexpr int WC = 4 / ACN, WR = 4 / WC;   // waves across the columns / the rows of the workgroup tile
+    constexpr int BM = 16 * ACC * WR, BN = 64, BK = 64, LD = BK + 4;
+    constexpr int NA = BM * (BK / 4) / 256;    // float4 loads per thread for the A tile (1, 2 or 4)
     constexpr int NB = BN * (BK / 4) / 256;    // 4
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+    extern __shared__ __attribute__((aligned(16))) float gemm_lds[];   // As[2][BM*LD] | Bs[2][BN*LD] (69.6 KB at BM = 64)
+    float (*As)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(gemm_lds);
+    float (*Bs)[BN * LD] = reinterpret_cast<float (*)[BN * LD]>(gemm_lds + 2 * BM * LD);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;  // this wave's block of the workgroup tile
     const int r = lane & 15, q = lane >> 4;
     const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int m0 = (int)(tile / gridDim.x) * BM, n0 = (int)(tile % gridDim.x) * BN;
@@ -238,12 +245,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
     const int c4t = tid & 15;                  // every float4 of this thread sits at k offset 4 * c4t of a chunk
 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[ACC];
+    f32x4 acc[ACC][ACN];
 #pragma unroll
-    for (int h = 0; h < ACC; ++h) acc[h] = zero;
-    // A wave whose 16 columns all lie beyond N only helps with the staging (the fifth column block of the lin GEMMs
+    for (int h = 0; h < ACC; ++h)
+#pragma unroll
+        for (int g = 0; g < ACN; ++g) acc[h][g] = zero;
+    // A wave whose columns all lie beyond N only helps with the staging (the fifth column block of the lin GEMMs
     // carries just the two attention columns): it skips the operand reads and the MFMAs.
-    const bool active = n0 + wave * 16 < N;
+    const bool active = n0 + wc * 16 * ACN < N;
 #ifdef NSC_DEV_TUNING
     f32x4 dev_c = {1.0f + (float)lane, 0.5f, 0.25f, 2.0f};
     asm volatile("" : "+v"(dev_c));
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
     // chunk's MFMAs run, so one L2 round trip is exposed per kernel instead of one per chunk (these GEMMs
     // are latency-bound: K = 256 is only 4 chunks).  A short last chunk (K % 64 != 0) re-reads valid
     // columns; those k-blocks are skipped below.
-    constexpr int PD = (ACC == 1) ? 4 : 3;
+    constexpr int PD = (ACC * WR == 1) ? 4 : 3;
     const int nchunks = K / BK + ((K % BK) ? 1 : 0);
     f32x4 ra[PD][NA], rb[PD][NB];
     auto load_chunk = [&](int ch, f32x4 (&xa)[NA], f32x4 (&xb)[NB]) {
@@ -290,24 +299,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
                 for (int d = 0; d < BK / 16; ++d) {
                     if (16 * d < kleft && active) {
 #ifdef NSC_DEV_TUNING
-                        if (ep.dev & 4) {                  // no LDS operand reads: MFMAs on whatever the registers hold
+                        if (ep.dev & 4) {                  // no LDS operand reads: MFMAs on loop-invariant registers
 #pragma unroll
                             for (int t = 0; t < 4; ++t)
 #pragma unroll
                                 for (int h = 0; h < ACC; ++h)
-                                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(dev_c[t], dev_c[3 - t], acc[h], 0, 0, 0);
+#pragma unroll
+                                    for (int g = 0; g < ACN; ++g)
+                                        acc[h][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(dev_c[t], dev_c[3 - t], acc[h][g], 0, 0, 0);
                             continue;
                         }
 #endif
-                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
-                        f32x4 av[ACC];
+                        f32x4 bv[ACN], av[ACC];
+#pragma unroll
+                        for (int g = 0; g < ACN; ++g)
+                            bv[g] = *reinterpret_cast<const f32x4 *>(&bs[(wc * 16 * ACN + 16 * g + r) * LD + 16 * d + 4 * q]);
 #pragma unroll
                         for (int h = 0; h < ACC; ++h)
-                            av[h] = *reinterpret_cast<const f32x4 *>(&as[(16 * h + r) * LD + 16 * d + 4 * q]);
+                            av[h] = *reinterpret_cast<const f32x4 *>(&as[(wr * 16 * ACC + 16 * h + r) * LD + 16 * d + 4 * q]);
 #ifdef NSC_DEV_TUNING
                         if (ep.dev & 1) {                  // no MFMAs: keep the operand reads alive
 #pragma unroll
-                            for (int h = 0; h < ACC; ++h) acc[h] += av[h] * bv;
+                            for (int h = 0; h < ACC; ++h)
+#pragma unroll
+                                for (int g = 0; g < ACN; ++g) acc[h][g] += av[h] * bv[g];
                             continue;
                         }
 #endif
@@ -315,7 +330,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
                             for (int h = 0; h < ACC; ++h)
-                                acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+#pragma unroll
+                                for (int g = 0; g < ACN; ++g)
+                                    acc[h][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[g][t], acc[h][g], 0, 0, 0);
                     }
                 }
                 if (ch + 1 < nchunks) {
@@ -339,8 +356,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 #pragma unroll
     for (int h = 0; h < ACC; ++h)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)                     // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
-            Cs[(16 * h + 4 * q + reg) * LD + wave * 16 + r] = acc[h][reg];
+        for (int g = 0; g < ACN; ++g)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)                 // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+                Cs[(wr * 16 * ACC + 16 * h + 4 * q + reg) * LD + wc * 16 * ACN + 16 * g + r] = acc[h][g][reg];
     __syncthreads();
     const int cg = n0 + 4 * c4t;                               // first of this thread's 4 columns
     float bias[4] = {0.f, 0.f, 0.f, 0.f}, bn_scale[4] = {1.f, 1.f, 1.f, 1.f}, bn_shift[4] = {0.f, 0.f, 0.f, 0.f};
@@ -747,15 +766,22 @@ void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const
     // less operand traffic per MFMA) as soon as they still give >= 1.5 workgroups per CU; below that 16-row tiles, so
     // that every SIMD of the chip gets a wave -- these GEMMs are operand-latency-, not MFMA-bound.
     const long long w2 = (long long)((N + 63) / 64) * ((M + 31) / 32);
+    const long long w4 = (long long)((N + 63) / 64) * ((M + 63) / 64);
     bool two = w2 >= 384 && !coresident;
+    // 64 x 64 tiles with 32 x 32 wave tiles (a third less LDS traffic per FLOP) where they still give two workgroups to
+    // every CU (70 KB of LDS each): output_proj at M = 4 541 (923 tiles); input_proj and lin there have 284 / 355
+    bool four = w4 >= 512 && !coresident;
     unsigned pad = 0;
 #ifdef NSC_DEV_TUNING
     const int force = gat_tune_env("NSC_TUNE_GEMM_ACC", 0);
-    if (force == 1) two = false;
-    if (force == 2) two = !coresident;
+    if (force == 1) two = four = false;
+    if (force == 2) { two = !coresident; four = false; }
+    if (force == 4) four = !coresident;
     pad = (unsigned)gat_tune_env("NSC_TUNE_GEMM_LDSPAD", 0);
 #endif
-    const dim3 grid((N + 63) / 64, two ? (M + 31) / 32 : (M + 15) / 16);
+    const int bm = four ? 64 : two ? 32 : 16;
+    const dim3 grid((N + 63) / 64, (M + bm - 1) / bm);
+    const unsigned lds = (unsigned)(2 * (bm + 64) * 68 * sizeof(float)) + pad;
 #ifdef NSC_DEV_TUNING
     GemmEpi epd = ep;
     epd.dev = gat_tune_env("NSC_TUNE_GEMM_ABL", 0);
@@ -766,12 +792,21 @@ void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const
         // co-running encoder MORE (longer uninterrupted MFMA bursts), DESIGN.md section 7.
         hipLaunchKernelGGL((gemm_nt_direct_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N,
                            n_main, K, C, ldc, ep);
+    } else if (four) {
+        static bool opted = false;          // dynamic LDS above 64 KB is opted into once per kernel
+        if (!opted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_kernel<2, EPI, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            opted = true;
+        }
+        hipLaunchKernelGGL((gemm_nt_kernel<2, EPI, 2>), grid, dim3(256), lds, st, A, lda, B, ldb, Bx, M, N, n_main,
+                           K, C, ldc, ep);
     } else {
         if (two)
-            hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), pad, st, A, lda, B, ldb, Bx, M, N, n_main,
+            hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), lds, st, A, lda, B, ldb, Bx, M, N, n_main,
                                K, C, ldc, ep);
         else
-            hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), pad, st, A, lda, B, ldb, Bx, M, N, n_main,
+            hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), lds, st, A, lda, B, ldb, Bx, M, N, n_main,
                                K, C, ldc, ep);
     }
 #ifdef NSC_DEV_TUNING

@@ -4,6 +4,7 @@ usage: summarize_gat_profile.py gpurun_out/<tag> > profiles/<round>_gat_n4541_ro
 import collections
 import csv
 import glob
+import re
 import sys
 
 d = sys.argv[1]
@@ -18,9 +19,9 @@ PEAK = 157.3e12
 
 def key(name):
     if "gemm_nt" in name:
-        for k in FLOP:
-            if ", " + k in name:
-                return k
+        m = re.search(r"gemm_nt\w*kernel<\s*\d+,\s*(\d+)", name)     # <ACC, EPI[, ACN]>: the role is the EPI argument
+        if m and m.group(1) + ">" in FLOP:
+            return m.group(1) + ">"
     if "gat_aggregate" in name:
         return "agg"
     return None

@@ -135,6 +135,22 @@ def test_coresident_variant_is_bit_identical(n, edge_dim):
     _check(b, m, g)
 
 
+@pytest.mark.parametrize("n", [2496, 2497, 2561, 3071])
+def test_large_tile_variant_boundaries(n):
+    """output_proj switches to 64 x 64 workgroup tiles (32 x 32 wave tiles) once ceil(n / 64) * 13 >= 512, i.e. from
+    n = 2 497 on: sizes either side of the switch and with ragged last tiles -- bit-identical to the LDS-free set (whose
+    tiling never changes) and within the oracle bar."""
+    m = _model()
+    g = gm.synthetic_chain_graph(n, device="cuda", seed=n)
+    with torch.no_grad():
+        a = m(g)
+        m.gnn.coresident = True
+        b = m(g)
+        m.gnn.coresident = False
+    assert torch.equal(a, b)
+    _check(a, m, g)
+
+
 def test_coresident_other_dims():
     m = _model(edge_dim=2, hidden_dim=64, input_dim=48, output_dim=80)
     g = gm.synthetic_chain_graph(77, device="cuda", seed=4)

@@ -119,7 +119,7 @@ GAT_FLOP_PER_NODE = 2.0 * (800 * 256 + 3 * 256 * 256 + 256 * 800)      # SURVEY 
 MFMA_F32_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md: f32-input MFMA
 
 
-def measure_extras(enc, model, dev, n_local, scratch):
+def measure_extras(enc, model, dev, n_local, scratch, uniform):
     """Untimed side measurements reported next to the headline (rank 0, N = 1, after the timed region):
       * the GAT half alone on BASELINE configs[2] (4 541 keyframes, 18 158 edges): HIP-event time per forward and
         the f32-MFMA rate it amounts to (the rocprofv3 counter figures of the same workload are under profiles/);
@@ -161,19 +161,26 @@ def measure_extras(enc, model, dev, n_local, scratch):
             "note": "whole forward (8 launches) by HIP events; per-kernel durations and the MFMA counters "
                     "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32) are in profiles/r02_gat_n4541_*",
         }
-        orders = {}
+        # the three point orders interleaved, so that clock drift between "then" and "now" cannot pass for an effect of the
+        # order: 5 rounds of 8 launches each, median per order
+        sets = {"uniform": uniform}
         for order in ("azimuth_major", "ring_major"):
-            pts, off = synth.make_clouds_device(n_local, N_POINTS, dev, seed=77, order=order)
+            sets[order] = synth.make_clouds_device(n_local, N_POINTS, dev, seed=77, order=order)
+        times = {k: [] for k in sets}
+        for k, (pts, off) in sets.items():
             for _ in range(3):
                 enc.encode_points_batch((pts, off), out=scratch)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(20):
-                enc.encode_points_batch((pts, off), out=scratch)
-            b.record()
-            torch.cuda.synchronize(dev)
-            orders[order] = a.elapsed_time(b) / 20
-            del pts, off
+        for _ in range(5):
+            for k, (pts, off) in sets.items():
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(8):
+                    enc.encode_points_batch((pts, off), out=scratch)
+                b.record()
+                torch.cuda.synchronize(dev)
+                times[k].append(a.elapsed_time(b) / 8)
+        orders = {k: float(np.median(v)) for k, v in times.items()}
+        del sets
         out["encoder_input_order_ms"] = orders
     gc.enable()
     return out
@@ -330,7 +337,7 @@ def main():
         solo_ms = float(np.mean([a.elapsed_time(b) for a, b in solo]))
         extras = {}
         if rank == 0 and world == 1 and not args.no_extras:
-            extras = measure_extras(enc, model, dev, n_local, scratch)
+            extras = measure_extras(enc, model, dev, n_local, scratch, (pts, off))
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -378,8 +385,7 @@ def main():
         if extras:
             line["roofline_gat"] = extras["roofline_gat"]
             # the headline workload is the uniform-order batch; the same kernel alone on sensor-ordered clouds:
-            line["roofline"]["standalone_launch_ms_by_input_order"] = dict(
-                uniform=solo_ms, **extras["encoder_input_order_ms"])
+            line["roofline"]["standalone_launch_ms_by_input_order"] = dict(extras["encoder_input_order_ms"])
         if world == 1 and not args.no_cpu_baseline:
             cb, odesc = cpu_baseline(pts, off, model, min(args.cpu_sample, n_local))
             line["cpu_baseline"] = cb

@@ -126,9 +126,9 @@ def test_coresident_register_budget(lib, tmp_path):
             sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
             if name and vg and sc:
                 kernels[name.group(1)] = (int(vg.group(1)), int(sc.group(1)))
-    enc = [v for k, v in kernels.items() if "encode_fast_kernelILi8ELb1" in k]
+    enc = [v for k, v in kernels.items() if "encode_fast_kernelILi2ELb1" in k]
     assert len(enc) == 1, sorted(kernels)
-    assert enc[0][0] <= 96 and enc[0][1] == 0, f"encode_fast_kernel<8>: {enc[0][0]} VGPRs, {enc[0][1]} B scratch"
+    assert enc[0][0] <= 96 and enc[0][1] == 0, f"encode_fast_kernel<2>: {enc[0][0]} VGPRs, {enc[0][1]} B scratch"
     co = {k: v for k, v in kernels.items() if "gemm_nt_direct_kernel" in k or "gat_aggregate_kernelILi1ELi4ELb0" in k}
     assert len(co) >= 4, sorted(kernels)
     for k, (vg, sc) in co.items():

@@ -23,7 +23,7 @@ Commands (tools/collect_profiles.sh, published by tools/publish_bench_profiles.s
 (`--{a['step_path']}` pins the step path the un-profiled run's calibration chose). Full CSV: profiles/{T}_rocprof_kernel_stats.csv; PMC traffic of the encoder
 kernel: profiles/{T}_pmc_encoder.md; table by tools/summarize_profile.py.
 
-The step is the two-stream software pipeline (DESIGN.md section 5): `encode_fast_kernel<8>` of batch k+1 on one stream, the LDS-free GNN
+The step is the two-stream software pipeline (DESIGN.md section 5): `encode_fast_kernel<2>` of batch k+1 on one stream, the LDS-free GNN
 kernels of batch k (`gemm_nt_direct_kernel`, `gat_aggregate_kernel<1,4,false>`) beside it on a second one. The GNN kernel durations are
 co-running durations (alone: the minima; the LDS-tiled `gemm_nt_kernel` rows are the serial path's calibration steps).
 

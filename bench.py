@@ -113,7 +113,7 @@ def cpu_baseline(pts_dev, off_dev, model, n_sample):
     }, desc
 
 
-EV_EVERY = 1
+EV_EVERY = 4
 CALIB_STEPS = 30
 GAT_FLOP_PER_NODE = 2.0 * (800 * 256 + 3 * 256 * 256 + 256 * 800)      # 5.51 GFLOP at N = 4 541
 MFMA_F32_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md: f32-input MFMA
@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)   # skip the untimed side measurements
     ap.add_argument("--gnn-kernels", choices=["auto", "lds", "direct"], default="auto", help=argparse.SUPPRESS)
+    ap.add_argument("--ev-every", type=int, default=EV_EVERY, help=argparse.SUPPRESS)   # time every n-th encoder launch
     ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)      # force the one-stream path
     ap.add_argument("--pipelined", action="store_true", help=argparse.SUPPRESS)   # force the two-stream path
     args = ap.parse_args()
@@ -319,9 +320,10 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             # the encoder kernel is bracketed by HIP events on the stream it is launched on -> live per-launch
-            # duration for the roofline object.  Every launch is bracketed (EV_EVERY = 1): measured in round 2, the step
-            # time is the same with every launch, every 4th or every 50th launch timed.
-            desc_all, emb = path.step((pts, off), encoder_events=ev[k] if k % EV_EVERY == 0 else None, inputs_ready=True)
+            # duration for the roofline object.  Every EV_EVERY-th launch is bracketed: a pair of timing events costs the
+            # stream ~5.4 us of idle per bracketed launch (kernel traces of the same step with every launch / no launch
+            # timed, round 2: 12.7 vs 7.3 us between two encoder launches, period 335.3 vs 329.0 us).
+            desc_all, emb = path.step((pts, off), encoder_events=ev[k] if k % args.ev_every == 0 else None, inputs_ready=True)
         t_issue = time.perf_counter() - t0                  # host side only: all K steps enqueued
         sync()
         dt = time.perf_counter() - t0
@@ -342,7 +344,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[::EV_EVERY]]))
+    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[::args.ev_every]]))
 
     if rank == 0:
         value = n_total * args.steps / dt
@@ -375,7 +377,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "encode_fast_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "launch_ms": enc_ms, "launches_timed": len(ev[::EV_EVERY]),
+                "traffic": traffic, "launch_ms": enc_ms, "launches_timed": len(ev[::args.ev_every]),
                 "co_running": None if chosen == "serial" else "GNN forward of the previous batch on a second stream",
                 "standalone_launch_ms": solo_ms,
                 "standalone_frac": n_local * BYTES_PER_CLOUD / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -103,7 +103,8 @@ int nsc_encode_range_images(const float *imgs, int32_t n_images, int32_t rows,
 /* Intensity image of RangeImageProjector.project(points, keep_intensity=True) (reference range_image.py:216-228):
  * per pixel the maximum intensity over the points whose float32 range equals the pixel's minimum range, 0 where no
  * point fell (and never below 0: the reference max-reduces into a zero image).  points are (N,4) rows; range_raw is
- * the raw range image batch of the same clouds (out_raw of nsc_encode_clouds).  Intensities that are NaN are ignored. */
+ * the raw range image batch of the same clouds (out_raw of nsc_encode_clouds).  A NaN intensity among a pixel's closest
+ * points makes the pixel NaN (np.maximum.at propagates it; the result is the canonical quiet NaN). */
 int nsc_project_intensity(const float *points, const int64_t *cloud_offsets, int32_t n_clouds, int64_t total_points,
                           const NscEncParams *p, const float *range_raw, float *out_intensity, void *stream);
 

@@ -1158,7 +1158,8 @@ __global__ __launch_bounds__(NW * 64) void finish_kernel(
 // into a zero image).  `range` is the raw range image of the same cloud (sqrtf of the min squared range; sqrtf
 // is correctly rounded, so r == range[pix] is the reference's float32 comparison).  Positive floats order like
 // their bit patterns, so the maximum is an integer atomicMax; intensities <= 0 never raise the 0 the image
-// starts from, NaN intensities are ignored (numpy would propagate them).
+// starts from; a NaN intensity among a pixel's closest points makes the pixel NaN, as np.maximum.at does (:225) -- the
+// quiet NaN 0x7fc00000 orders above every positive float and +inf as an integer (payloads are not preserved).
 __global__ __launch_bounds__(256) void intensity_kernel(const float *__restrict__ pts, const long long *__restrict__ off,
                                                         int parts, NscBinParams bp, int npix,
                                                         const float *__restrict__ range, int *__restrict__ out)
@@ -1178,6 +1179,7 @@ __global__ __launch_bounds__(256) void intensity_kernel(const float *__restrict_
         if (!nsc_point_pixel(v.x, v.y, v.z, bp, pix, s)) continue;
         if (sqrtf(s) != rng[pix]) continue;
         if (v.w > 0.0f) atomicMax(&o[pix], __float_as_int(v.w));
+        else if (v.w != v.w) atomicMax(&o[pix], 0x7fc00000);     // np.maximum propagates NaN: above every number, +inf included
     }
 }
 

@@ -29,10 +29,15 @@ def cloud(n, seed):
 
 cases = []
 seed = 100
-while len(cases) < 3:                                 # clouds on which oracle and reference agree on every pixel
-    n = [20000, 8000, 25000][len(cases)]
+while len(cases) < 4:                                 # clouds on which oracle and reference agree on every pixel
+    n = [20000, 8000, 25000, 12000][len(cases)]
     p = cloud(n, seed)
     seed += 1
+    if len(cases) == 3:                               # NaN / +inf intensities: np.maximum.at propagates NaN (:225)
+        p[::37, 3] = np.nan                           # some of these are a pixel's closest point, some are not
+        p[5::101, 3] = np.inf
+        p[2000:2300, :3] = p[:300, :3]                # exact range ties: NaN next to a number on the same pixel
+        p[2000:2300:2, 3] = np.nan
     if len(cases) == 1:                               # exact range ties inside a pixel: duplicated points, different intensity
         p[1000:2000, :3] = p[:1000, :3]
         p[1000:2000, 3] = rng.uniform(0, 2, 1000).astype(np.float32)
@@ -46,5 +51,5 @@ while len(cases) < 3:                                 # clouds on which oracle a
     k = f"c{len(cases)}"
     out[k + "_pts"], out[k + "_range"], out[k + "_intensity"] = p, rimg.astype(np.float32), iimg.astype(np.float32)
     cases.append(k)
-    print(k, n, "seed", seed - 1, "pixels with intensity", int((iimg > 0).sum()))
+    print(k, n, "seed", seed - 1, "pixels with intensity", int((iimg > 0).sum()), "NaN pixels", int(np.isnan(iimg).sum()))
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "intensity.npz"), **out)

@@ -300,7 +300,7 @@ def test_intensity_image_matches_reference():
     from neural_spectral_codec_amd.encoding.range_image import RangeImageProjector
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intensity.npz"))
     proj = RangeImageProjector(n_elevation=16, n_azimuth=360, device="cuda")
-    for k in ("c0", "c1", "c2"):
+    for k in ("c0", "c1", "c2", "c3"):                  # c3: NaN / +inf intensities (np.maximum.at propagates NaN)
         pts = g[k + "_pts"]
         rimg, iimg = proj.project(pts, keep_intensity=True)
         assert rimg.dtype == np.float32 and iimg.dtype == np.float32 and iimg.shape == (16, 360)

@@ -118,11 +118,12 @@ def test_intensity_oracle_matches_reference():
     """nsc_oracle.project_intensity vs the reference's project(keep_intensity=True) (tests/golden/intensity.npz)."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intensity.npz"))
-    for k in ("c0", "c1", "c2"):
+    for k in ("c0", "c1", "c2", "c3"):                  # c3: NaN / +inf intensities (np.maximum.at propagates NaN)
         img, inten = orc.project_intensity(g[k + "_pts"])
         assert (img.view(np.uint32) == g[k + "_range"].view(np.uint32)).all(), k
         assert (inten.view(np.uint32) == g[k + "_intensity"].view(np.uint32)).all(), k
-        assert inten.min() >= 0.0 and (inten > 0).sum() > 1000
+        assert np.nanmin(inten) >= 0.0 and (inten > 0).sum() > 1000
+    assert np.isnan(g["c3_intensity"]).sum() > 100
 
 
 def test_nearest_interpolation_oracle_matches_reference(golden_dir):

@@ -107,12 +107,13 @@ def test_ragged_batch_and_empty_clouds():
 
 
 def test_fast_kernel_window_edges():
-    """encode_fast_kernel streams a cloud in rounds of 8 x 256 points with a rolling window of loads: cloud sizes
-    around every boundary of that scheme (one lane, one wave, one workgroup pass, one round, several rounds +- 1),
-    all in ONE batch so that every workgroup takes a different path through the prologue / main loop / tail."""
+    """encode_fast_kernel streams a cloud in rounds of U x 256 points with a rolling window of loads (U = 2 ships, 8 in
+    round-2 development builds): cloud sizes around every boundary of both schemes (one lane, one wave, one workgroup
+    pass, one round, several rounds +- 1), all in ONE batch so that every workgroup takes a different path through the
+    prologue / main loop / tail."""
     enc = _enc()
-    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 511, 2047, 2048, 2049, 2303, 2304, 4095, 4096, 4097, 6143, 6144, 6145,
-             8191, 8192, 20479, 20480, 20481, 33333]
+    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2048, 2049, 2303,
+             2304, 4095, 4096, 4097, 6143, 6144, 6145, 8191, 8192, 20479, 20480, 20481, 33333]
     clouds = [synth.make_cloud(900 + i, n, ("uniform", "wide", "adversarial")[i % 3]) for i, n in enumerate(sizes)]
     assert [len(c) for c in clouds] == sizes
     d, raw, itp = enc.encode_points_batch(clouds, return_images=True)

@@ -120,7 +120,8 @@ def project_intensity(points, p=None):
     li = idx[keep].astype(np.int64)
     closest = r == flat[li]                                                                      # :222
     out = np.zeros(flat.shape, dtype=np.float32)                                                 # :219
-    np.maximum.at(out, li[closest], pts[keep, 3][closest])                                       # :225
+    with np.errstate(invalid="ignore"):             # NaN intensities propagate, as in the reference; numpy merely warns
+        np.maximum.at(out, li[closest], pts[keep, 3][closest])                                   # :225
     return img, out.reshape(img.shape)
 
 

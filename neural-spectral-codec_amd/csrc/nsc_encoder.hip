@@ -834,7 +834,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
                                             float *__restrict__ out_desc, float *__restrict__ out_raw,
                                             float *__restrict__ out_interp)
 {
-    constexpr int NW = 4, NT = 256, E = 16;
+    constexpr int E = 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = d.B;
     const FastLds lp = fast_lds(B);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NSC_ABI_VERSION 2
+#define NSC_ABI_VERSION 3
 
 typedef enum NscStatus {
     NSC_OK            = 0,
@@ -67,6 +67,16 @@ void nsc_enc_default_params(NscEncParams *p);
  * cloud kernel is used; non-zero when clouds are split across workgroups). */
 size_t nsc_encode_clouds_workspace_bytes(int32_t n_clouds, int64_t total_points,
                                          const NscEncParams *p);
+
+/* Which kernel set nsc_encode_clouds launches for a batch of this shape (the launcher calls the same decision
+ * function): NSC_ENC_PATH_FAST = encode_fast_kernel, the streaming kernel of the configuration every reference caller
+ * uses (16 x 360 image, no pooling, (N,4) points, default FOV / range window; any number of clouds, a single cloud of
+ * >= 2^27 points takes a slower loop inside it); NSC_ENC_PATH_FUSED = encode_fused_kernel (any other shape);
+ * NSC_ENC_PATH_SPLIT = scatter_split_kernel + finish_kernel (few large clouds).  Negative = NscStatus error. */
+#define NSC_ENC_PATH_FAST 1
+#define NSC_ENC_PATH_FUSED 2
+#define NSC_ENC_PATH_SPLIT 3
+int nsc_encode_clouds_path(int32_t n_clouds, int64_t total_points, int32_t stride_floats, const NscEncParams *p);
 
 /* SpectralEncoder.encode_points for a packed batch of clouds.
  *   pts            (total_points, stride) float32, row-major AoS [x,y,z(,intensity)]; stride 3 or 4

@@ -30,7 +30,7 @@ class GatLayer(C.Structure):
         "bn_w", "bn_b", "bn_mean", "bn_var")]
 
 
-ABI_VERSION = 2            # NSC_ABI_VERSION of include/nsc.h
+ABI_VERSION = 3            # NSC_ABI_VERSION of include/nsc.h
 GAT_MAX_LAYERS = 8
 GAT_MAX_EDGE_DIM = 8
 
@@ -93,6 +93,7 @@ SYMBOLS = {
     "nsc_status_string": (C.c_char_p, [C.c_int]),
     "nsc_enc_default_params": (None, [_pp]),
     "nsc_encode_clouds_workspace_bytes": (_sz, [_i32, _i64, _pp]),
+    "nsc_encode_clouds_path": (C.c_int, [_i32, _i64, _i32, _pp]),
     "nsc_encode_clouds": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nsc_project_intensity": (C.c_int, [_vp, _vp, _i32, _i64, _pp, _vp, _vp, _vp]),
     "nsc_scatter_clouds": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _pp, _vp, _vp]),

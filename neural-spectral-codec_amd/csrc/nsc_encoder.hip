@@ -300,7 +300,13 @@ __device__ __forceinline__ void fft_load_row(const float *x, int lane, f32x2 (&i
 // inter-stage twiddles depend on the lane only and are read once for all rows.  Returns |X[k]| of row p for
 // k = lane + 64 jj in mg[p][jj] (0 beyond k = 180); every read of buf precedes the return in program order, so the
 // caller may store the magnitudes over the scratch.
-template <int NR>
+// LEAN = true keeps the same arithmetic (same operations on the same operands: bit-identical results) but runs stages
+// 2-4 one row after the other -- the caller of the first pair of a wave holds the second pair's 16 stage-1 registers
+// through it, and with them the interleaved stages 3/4 take 82 VGPRs, the sequential ones 72.  The radix-5 stage is
+// sequential in both forms and reads its four twiddles one at a time (all four at once: 88 VGPRs).  The register
+// budget is what lets five encoder workgroups AND two waves of the co-resident GNN kernels share a SIMD
+// (5 x 80 + 2 x 56 = 512; tests/test_abi_cpu.py::test_coresident_register_budget).
+template <int NR, bool LEAN = false>
 __device__ __forceinline__ void fft_rows(const f32x2 (*in)[4], double2 *const (&buf)[NR], const double2 *tw,
                                          float (&mg)[NR][3], int lane)
 {
@@ -319,15 +325,9 @@ __device__ __forceinline__ void fft_rows(const f32x2 (*in)[4], double2 *const (&
     }
     wave_sync();
     {   // stage 2: R = 5, Ns = 4, 36 butterflies, W = W360^(18 r k).  One row after the other (each in place in its
-        // own buffer): two radix-5 butterflies in flight are 40 more live registers than the kernel's budget beside
-        // the GNN waves allows, and the only stage where that is so.
+        // own buffer), the twiddles read one at a time: this stage is the register peak of the whole kernel.
         const int k = lane & 3;
         const int j0 = (lane >> 2) * 20 + k;
-        double2 w[5];
-        if (lane < 36) {
-#pragma unroll
-            for (int r = 1; r < 5; ++r) w[r] = tw[18 * r * k];
-        }
 #pragma unroll
         for (int p = 0; p < NR; ++p) {
             double re[5], im[5];
@@ -338,7 +338,11 @@ __device__ __forceinline__ void fft_rows(const f32x2 (*in)[4], double2 *const (&
                     re[r] = v.x; im[r] = v.y;
                 }
 #pragma unroll
-                for (int r = 1; r < 5; ++r) twmul(re[r], im[r], w[r]);
+                for (int r = 1; r < 5; ++r) {
+                    const double2 w = tw[18 * r * k];
+                    twmul(re[r], im[r], w);
+                    asm volatile("" ::: "memory");     // keeps the four reads from being hoisted together (16 registers)
+                }
                 dft5(re, im);
             }
             wave_sync();
@@ -349,62 +353,62 @@ __device__ __forceinline__ void fft_rows(const f32x2 (*in)[4], double2 *const (&
         }
     }
     wave_sync();
-    {   // stage 3: R = 3, Ns = 20, 60 butterflies, W = W360^(6 r k)
-        double re[NR][3], im[NR][3];
+    // stages 3 and 4: R = 3, 60 butterflies each; stage 3: Ns = 20, W = W360^(6 r k), k = lane mod 20, output index
+    // (lane div 20) 60 + k + 20 q; stage 4: Ns = 60, W = W360^(2 r lane), output index lane + 60 q
+#pragma unroll
+    for (int st = 3; st <= 4; ++st) {
         const int k = lane % 20;
+        const int j0 = (st == 3) ? (lane / 20) * 60 + k : lane;
+        const int qs = (st == 3) ? 20 : 60;
+        double2 w1 = {0.0, 0.0}, w2 = {0.0, 0.0};
         if (lane < 60) {
-            const double2 w1 = tw[6 * k], w2 = tw[12 * k];
-#pragma unroll
-            for (int p = 0; p < NR; ++p)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const double2 v = buf[p][lane + 60 * r];
-                    re[p][r] = v.x; im[p][r] = v.y;
-                }
+            w1 = tw[(st == 3) ? 6 * k : 2 * lane];
+            w2 = tw[(st == 3) ? 12 * k : 4 * lane];
+        }
+        if (LEAN) {
 #pragma unroll
             for (int p = 0; p < NR; ++p) {
-                twmul(re[p][1], im[p][1], w1);
-                twmul(re[p][2], im[p][2], w2);
-                dft3(re[p], im[p]);
+                double re[3], im[3];
+                if (lane < 60) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { const double2 v = buf[p][lane + 60 * r]; re[r] = v.x; im[r] = v.y; }
+                    twmul(re[1], im[1], w1);
+                    twmul(re[2], im[2], w2);
+                    dft3(re, im);
+                }
+                wave_sync();
+                if (lane < 60) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { double2 o; o.x = re[q]; o.y = im[q]; buf[p][j0 + qs * q] = o; }
+                }
+            }
+        } else {
+            double re[NR][3], im[NR][3];
+            if (lane < 60) {
+#pragma unroll
+                for (int p = 0; p < NR; ++p)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const double2 v = buf[p][lane + 60 * r];
+                        re[p][r] = v.x; im[p][r] = v.y;
+                    }
+#pragma unroll
+                for (int p = 0; p < NR; ++p) {
+                    twmul(re[p][1], im[p][1], w1);
+                    twmul(re[p][2], im[p][2], w2);
+                    dft3(re[p], im[p]);
+                }
+            }
+            wave_sync();
+            if (lane < 60) {
+#pragma unroll
+                for (int p = 0; p < NR; ++p)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { double2 o; o.x = re[p][q]; o.y = im[p][q]; buf[p][j0 + qs * q] = o; }
             }
         }
         wave_sync();
-        if (lane < 60) {
-            const int j0 = (lane / 20) * 60 + k;
-#pragma unroll
-            for (int p = 0; p < NR; ++p)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) { double2 o; o.x = re[p][q]; o.y = im[p][q]; buf[p][j0 + 20 * q] = o; }
-        }
     }
-    wave_sync();
-    {   // stage 4: R = 3, Ns = 60, 60 butterflies, W = W360^(2 r k), k = j
-        double re[NR][3], im[NR][3];
-        if (lane < 60) {
-            const double2 w1 = tw[2 * lane], w2 = tw[4 * lane];
-#pragma unroll
-            for (int p = 0; p < NR; ++p)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const double2 v = buf[p][lane + 60 * r];
-                    re[p][r] = v.x; im[p][r] = v.y;
-                }
-#pragma unroll
-            for (int p = 0; p < NR; ++p) {
-                twmul(re[p][1], im[p][1], w1);
-                twmul(re[p][2], im[p][2], w2);
-                dft3(re[p], im[p]);
-            }
-        }
-        wave_sync();
-        if (lane < 60) {
-#pragma unroll
-            for (int p = 0; p < NR; ++p)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) { double2 o; o.x = re[p][q]; o.y = im[p][q]; buf[p][lane + 60 * q] = o; }
-        }
-    }
-    wave_sync();
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {                   // unpack the real spectrum, |X[k]| -> float32
         const int k = lane + 64 * jj;
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void encode_fused_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int FQ_CAP = TW_N;               // 240 queue entries of 16 B in the bytes the twiddle table occupies later
 constexpr int FAST_HSTRIDE = 64;           // floats between the histograms of a wave's four rows (n_bins <= 64)
-constexpr long long FAST_MAX_POINTS = 1LL << 27;   // per cloud: byte offsets stay below 2^31
+constexpr long long FAST_MAX_POINTS = 1LL << 27;   // per cloud: byte offsets stay below 2^31 (tested in the kernel)
 
 struct FastLds {
     int img, aux, seg, misc, total;
@@ -727,8 +731,10 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
     };
     // wave-uniform base address in SGPRs + a 32-bit byte offset per lane (clouds hold < 2^27 points)
     const unsigned long long pa = reinterpret_cast<unsigned long long>(P);
-    const unsigned long long Pb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
+    unsigned long long Pb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pa);
+    // callers guarantee 0 < n < FAST_MAX_POINTS (encode_fast_kernel tests both): n = 0 would make `last` wrap and
+    // every clamp below a no-op, n >= 2^27 would wrap the 32-bit byte offsets
     const unsigned last = (unsigned)(n - 1) * 16u;                  // loads past the cloud re-read its last point
     const int T = (n + NT * U - 1) / (NT * U);                      // rounds, the last one possibly partial
     f32x4 buf[U];
@@ -739,13 +745,19 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
     asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(slot) : "v"(ofs), "s"(base_) : "memory")
 #define NSC_SLOT_WAIT2(s0, s1, cnt) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s0), "+v"(s1) : "i"(cnt) : "memory")
 
+    // v_readfirstlane writes the SGPR pair; a VMEM instruction that reads it as its scalar base needs 5 wait states
+    // after a VALU write, and the hazard recogniser does not look inside inline asm.  The s_nop takes the base as an
+    // in/out operand: it cannot be scheduled before the SGPRs are written, and every load below reads ITS result, so
+    // none can be scheduled before it.  (A dangling `asm volatile("s_nop 4")` orders nothing against the
+    // readfirstlane -- a development variant with a per-wave base faulted on address 0 in round 2, the stale-SGPR
+    // signature; in the shipped kernel the compiler proves the base uniform and computes it on the SALU.)
+    asm volatile("s_nop 4" : "+s"(Pb) : : "memory");
     unsigned o = (unsigned)tid * 16u;                               // byte offset of slot 0 of the current round
     static_for<U>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         f32x4 &slot = buf[u];
         const unsigned long long base_ = Pb;
         const unsigned a = min(o + (unsigned)(u * NT * 16), last);
-        if (u == 0) asm volatile("s_nop 4" ::: "memory");           // readfirstlane -> SGPR base of a VMEM (hazard)
         NSC_SLOT_LOAD(slot, a);
     });
     constexpr unsigned RB = (unsigned)(U * NT * 16);                 // bytes per round
@@ -811,6 +823,24 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
 #ifdef NSC_DEV_TUNING
     if (dev_mode & (64 | 128)) atomicMin(&img[tid & 63], __float_as_uint(fabsf(dev_acc)));
 #endif
+}
+
+// Cold path of encode_fast_kernel: the whole cloud through the lean estimate, one point per thread and iteration,
+// uncertain points resolved in place with the exact chain.  Runs for (a) a cloud that parked more uncertain points than
+// the queue holds (adversarial clouds on bin edges) -- min is idempotent, so the pixels the stream already wrote stay
+// right -- and (b) a cloud of >= FAST_MAX_POINTS points, whose byte offsets do not fit the 32 bits stream_fast uses
+// (64-bit indexing here).  Deliberately not unrolled: four exact chains in flight (scatter_range<NT, 4>, round 2) were
+// the kernel's register peak, 92 VGPRs.
+__device__ __forceinline__ void restream_cold(const f32x4 *__restrict__ P, long long n, int tid, int nt,
+                                              const NscBinParams &bp, unsigned *img)
+{
+    for (long long i = tid; i < n; i += nt) {
+        const f32x4 v = __builtin_nontemporal_load(&P[i]);
+        int pix; float s; bool certain;
+        if (!nsc_point_lean_flags(v.x, v.y, v.z, bp, pix, s, certain)) continue;
+        if (!certain) pix = nsc_point_exact(v.x, v.y, v.z, bp);
+        atomicMin(&img[pix], __float_as_uint(s));
+    }
 }
 
 // The tables the finish needs from global memory, one element per thread; their latency lands under the square roots
@@ -942,7 +972,10 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
         float mg[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-        if (!NSC_DEV_SKIP(d, 4)) fft_rows<2>(in + 2 * pr, bufs, tw, mg, lane);
+        if (!NSC_DEV_SKIP(d, 4)) {            // pair 0 carries pair 1's stage-1 operands: the lean form (see fft_rows)
+            if (pr == 0) fft_rows<2, true>(in, bufs, tw, mg, lane);
+            else fft_rows<2, false>(in + 2, bufs, tw, mg, lane);
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             float *mags = reinterpret_cast<float *>(bufs[p]);
@@ -1002,7 +1035,7 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
 }
 
 template <int U, bool PAIR = true>
-__global__ __launch_bounds__(256, 5) void encode_fast_kernel(
+__global__ __launch_bounds__(256, 6) void encode_fast_kernel(
     const float *__restrict__ pts, const long long *__restrict__ off, EncDev d, const int *__restrict__ lut,
     float *__restrict__ out_desc, float *__restrict__ out_raw, float *__restrict__ out_interp)
 {
@@ -1021,15 +1054,16 @@ __global__ __launch_bounds__(256, 5) void encode_fast_kernel(
     }
     __syncthreads();
     const long long p0 = off[c];
-    const int n = (int)(off[c + 1] - p0);                           // < 2^27 (host check)
+    const long long n64 = off[c + 1] - p0;
+    const f32x4 *P = reinterpret_cast<const f32x4 *>(pts) + p0;
+    // the size limit of the streaming loop is PER CLOUD (32-bit byte offsets relative to the cloud's own base); a
+    // cloud beyond it takes the cold loop, the rest of the batch is unaffected
+    const bool streamable = n64 > 0 && n64 < FAST_MAX_POINTS;
+    const int n = streamable ? (int)n64 : 0;
 #ifdef NSC_DEV_TUNING
     const unsigned long long dev_t0 = wall_clock64();
     unsigned long long dev_t1 = 0;
-#endif
-#ifdef NSC_DEV_TUNING
     if (NSC_DEV_SKIP(d, 32)) __builtin_amdgcn_s_setprio(3);
-#endif
-#ifdef NSC_DEV_TUNING
     if (d.dev_stagger > 0) {          // workgroups b, b + 256, b + 512, b + 768 are expected to share a CU
         const int units = ((blockIdx.x >> 8) & 3) * d.dev_stagger;
         for (int u = 0; u < units; u += 100) __builtin_amdgcn_s_sleep(100);
@@ -1037,23 +1071,21 @@ __global__ __launch_bounds__(256, 5) void encode_fast_kernel(
 #endif
     if (n > 0 && !NSC_DEV_SKIP(d, 2))
 #ifdef NSC_DEV_TUNING
-        stream_fast<NT, U, PAIR>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount, d.dev_skip);
+        stream_fast<NT, U, PAIR>(P, n, tid, d.bp, img, queue, qcount, d.dev_skip);
 #else
-        stream_fast<NT, U, PAIR>(reinterpret_cast<const f32x4 *>(pts) + p0, n, tid, d.bp, img, queue, qcount);
+        stream_fast<NT, U, PAIR>(P, n, tid, d.bp, img, queue, qcount);
 #endif
     __syncthreads();
     {   // drain the uncertain-point queue with the exact chain (the definition of the pixel), compacted
         const unsigned qn = *qcount;
-        if (qn <= (unsigned)FQ_CAP) {
+        if (qn <= (unsigned)FQ_CAP && (streamable || n64 <= 0)) {
             for (unsigned i = tid; i < qn; i += NT) {
                 const f32x4 e = queue[i];
                 atomicMin(&img[nsc_point_exact(e.x, e.y, e.z, d.bp)], __float_as_uint(e.w));
             }
         } else {
-            // More uncertain points than the queue holds (an adversarial cloud parked on bin edges): some were not
-            // recorded.  Stream the cloud again with the generic per-point path, which resolves them in place; min
-            // is idempotent, so the pixels already written stay right.
-            scatter_range<NT, 4>(pts, p0, p0 + n, 4, tid, d.bp, img);
+            // queue overflow (some uncertain points were not recorded) or a cloud too large for the streaming loop
+            restream_cold(P, n64, tid, NT, d.bp, img);
         }
     }
     __syncthreads();
@@ -1259,6 +1291,21 @@ EncDev make_dev(const NscEncParams *p, int rows_in)
     return d;
 }
 
+int split_parts(int32_t n_clouds, int64_t total_points);
+
+// Which kernel set nsc_encode_clouds launches for a batch: the one decision function the launcher and
+// nsc_encode_clouds_path() share.
+int encode_path(const EncDev &d, int32_t n_clouds, int64_t total_points, int32_t stride, int variant)
+{
+    if (split_parts(n_clouds, total_points) > 1) return NSC_ENC_PATH_SPLIT;
+    // the configuration of every reference caller: the lean streaming kernel.  No limit on the batch: the kernel's
+    // 32-bit byte offsets are relative to each cloud's own base, and a single cloud of >= 2^27 points takes its cold
+    // loop (round 2 tested total_points here and sent batches of more than 1 118 x 120 000 points to the generic kernel).
+    if (variant <= 0 && stride == 4 && d.E == 16 && d.R == 16 && d.B <= FAST_HSTRIDE && nsc_lean_ok(d.bp))
+        return NSC_ENC_PATH_FAST;
+    return NSC_ENC_PATH_FUSED;
+}
+
 int split_parts(int32_t n_clouds, int64_t total_points)
 {
     const int force = tune_env("NSC_TUNE_SPLIT", 0);
@@ -1322,6 +1369,14 @@ size_t nsc_encode_clouds_workspace_bytes(int32_t n_clouds, int64_t total_points,
     return (size_t)n_clouds * p->n_elevation * A * sizeof(unsigned);
 }
 
+int nsc_encode_clouds_path(int32_t n_clouds, int64_t total_points, int32_t stride, const NscEncParams *p)
+{
+    int st = check_params(p);
+    if (st != NSC_OK) return st;
+    if (n_clouds < 0 || total_points < 0 || (stride != 3 && stride != 4)) return NSC_EINVAL;
+    return encode_path(make_dev(p, p->n_elevation), n_clouds, total_points, stride, tune_env("NSC_TUNE_VARIANT", 0));
+}
+
 int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_clouds,
                       int64_t total_points, int32_t stride, const NscEncParams *p, const int32_t *lut,
                       float *out_desc, float *out_raw, float *out_interp, void *ws, size_t ws_bytes,
@@ -1338,12 +1393,11 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
     const LdsPlan lp = lds_plan(d.E, d.R, d.B, FUSED_NW);
     const int parts = split_parts(n_clouds, total_points);
     const long long *off = reinterpret_cast<const long long *>(cloud_offsets);
+    const int variant = tune_env("NSC_TUNE_VARIANT", 0);
+    const int path = encode_path(d, n_clouds, total_points, stride, variant);
 
-    if (parts <= 1) {
-        const int variant = tune_env("NSC_TUNE_VARIANT", 0);
-        // the configuration of every reference caller: the lean streaming kernel
-        if (variant <= 0 && stride == 4 && d.E == 16 && d.R == 16 && d.B <= FAST_HSTRIDE && nsc_lean_ok(d.bp) &&
-            total_points < FAST_MAX_POINTS) {
+    if (path != NSC_ENC_PATH_SPLIT) {
+        if (path == NSC_ENC_PATH_FAST) {
             const FastLds fl = fast_lds(d.B);
 #ifdef NSC_DEV_TUNING
             if (variant == -1)

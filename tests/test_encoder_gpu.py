@@ -149,6 +149,61 @@ def test_fast_kernel_uncertain_queue_overflow():
         assert _close(d[i].cpu().numpy(), od, 1e-6, 1e-9), i
 
 
+def test_large_batch_stays_on_the_fast_kernel():
+    """1 200 clouds x 120 000 points = 144 M points (2.3 GB): beyond the 2^27-point BATCH limit that sent anything above
+    1 118 such clouds to the generic kernel in round 2.  The limit the kernel needs is per cloud; the launcher's own
+    decision function must say "fast" for this batch, and the result must not depend on how the batch is cut: every
+    cloud's descriptor equals, bit for bit, the one it gets in a 1 024-cloud / 176-cloud launch; sampled clouds equal
+    the oracle."""
+    from neural_spectral_codec_amd import _lib
+    enc = _enc()
+    n, npts = 1200, 120000
+    L = _lib.lib()
+    assert L.nsc_encode_clouds_path(n, n * npts, 4, enc._params()) == 1            # NSC_ENC_PATH_FAST
+    assert L.nsc_encode_clouds_path(5000, 5000 * npts, 4, enc._params()) == 1
+    assert L.nsc_encode_clouds_path(n, n * npts, 3, enc._params()) == 2            # (N,3) points: generic kernel
+    assert L.nsc_encode_clouds_path(3, 3 * npts, 4, enc._params()) == 3            # few big clouds: split path
+    pts, off = synth.make_clouds_device(n, npts, "cuda", seed=21)
+    d = enc.encode_points_batch((pts, off))
+    torch.cuda.synchronize()
+    assert torch.allclose(d.sum(1), torch.ones(n, device="cuda"), atol=1e-5)
+    d_a = enc.encode_points_batch((pts[:1024 * npts], off[:1025]))
+    d_b = enc.encode_points_batch((pts[1024 * npts:], off[1024:] - off[1024]))
+    assert torch.equal(d[:1024], d_a) and torch.equal(d[1024:], d_b)
+    for c in (0, 1118, 1119, 1199):
+        host = pts[c * npts:(c + 1) * npts].cpu().numpy()
+        assert _close(d[c].cpu().numpy(), orc.encode_points(host), 1e-6, 1e-9), c
+
+
+def test_cloud_beyond_the_streaming_limit_inside_a_fast_batch():
+    """ONE cloud of 2^27 + 37 points (2.1 GB) among 511 small ones: the batch is launched on the fast kernel, whose
+    streaming loop addresses a cloud with 32-bit byte offsets; the workgroup of the big cloud must take the kernel's
+    64-bit cold loop, the others the stream.  Raw / interpolated image of the big cloud bit-exact against the oracle."""
+    from neural_spectral_codec_amd import _lib
+    enc = _enc()
+    big = (1 << 27) + 37
+    small = [synth.make_cloud(4000 + i, 100 + i, "uniform") for i in range(511)]
+    bp, _ = synth.make_clouds_device(1, big, "cuda", seed=5)
+    sp = torch.from_numpy(np.concatenate(small, 0)).cuda()
+    k = 200                                                       # the big cloud sits in the middle of the batch
+    n_before = sum(len(c) for c in small[:k])
+    pts = torch.cat([sp[:n_before], bp, sp[n_before:]], 0).contiguous()
+    sizes = [len(c) for c in small[:k]] + [big] + [len(c) for c in small[k:]]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device="cuda")
+    del bp, sp
+    assert _lib.lib().nsc_encode_clouds_path(512, int(pts.shape[0]), 4, enc._params()) == 1
+    d, raw, itp = enc.encode_points_batch((pts, off), return_images=True)
+    torch.cuda.synchronize()
+    host = pts[n_before:n_before + big].cpu().numpy()
+    od, oraw, oitp = orc.encode_points(host, want_images=True)
+    assert np.array_equal(raw[k].cpu().numpy().view(np.uint32), oraw.view(np.uint32))
+    assert np.array_equal(itp[k].cpu().numpy().view(np.uint32), oitp.view(np.uint32))
+    assert _close(d[k].cpu().numpy(), od, 1e-6, 1e-9)
+    for i in (0, k - 1, k + 1, 511):
+        c = small[i if i < k else i - 1]
+        assert _close(d[i].cpu().numpy(), orc.encode_points(c), 1e-6, 1e-9), i
+
+
 def test_split_path_small_batch_of_big_clouds():
     """3 x 120k points: clouds are split over workgroups and merged with global atomicMin."""
     enc = _enc()

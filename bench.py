@@ -200,7 +200,9 @@ def main():
     ap.add_argument("--gnn-kernels", choices=["auto", "lds", "direct"], default="auto", help=argparse.SUPPRESS)
     ap.add_argument("--ev-every", type=int, default=EV_EVERY, help=argparse.SUPPRESS)   # time every n-th encoder launch
     ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)      # force the one-stream path
-    ap.add_argument("--pipelined", action="store_true", help=argparse.SUPPRESS)   # force the two-stream path
+    ap.add_argument("--pipelined", action="store_true", help=argparse.SUPPRESS)   # force the software-pipelined path
+    # consecutive encoder launches alternate over this many streams (2: they overlap); 0 = let the calibration choose
+    ap.add_argument("--enc-streams", type=int, default=0, choices=[0, 1, 2], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,7 +230,6 @@ def main():
     from neural_spectral_codec_amd import distributed as nd
     from neural_spectral_codec_amd.encoding import SpectralEncoder
     from neural_spectral_codec_amd.gnn.model import create_spectral_gnn
-    import gat_oracle as go
 
     n_local = args.clouds
     n_total = n_local * world
@@ -237,7 +238,7 @@ def main():
     torch.manual_seed(0)                                    # identical random-init weights on all ranks
     model = create_spectral_gnn(input_dim=800, hidden_dim=256, output_dim=800, n_layers=3,
                                 dropout=0.1, edge_dim=2)
-    go.randomize_bn_stats(model)
+    synth.randomize_bn_stats(model)
     model = model.to(dev).eval()
     pts, off = synth.make_clouds_device(n_local, N_POINTS, dev, seed=1234 + rank)
     poses = synth.make_pose_chain(n_total, 0)
@@ -255,16 +256,26 @@ def main():
         def encode_points_batch(clouds):
             return enc.encode_points_batch(clouds, out=desc_local)
 
-    def make_path(pipelined):
-        p_ = nd.ShardedDescriptorPath(enc, model, n_total, poses, pipeline=pipelined)
+    def make_path(pipelined, enc_streams=1):
+        p_ = nd.ShardedDescriptorPath(enc, model, n_total, poses, pipeline=pipelined, encoder_streams=enc_streams)
         if not pipelined:
             p_.encoder = _Enc
         return p_
 
     inner_gnn = getattr(model, "gnn", model)
-    paths = {"pipelined": make_path(True), "serial": make_path(False)}
-    paths["pipelined"].coresident_gnn = args.gnn_kernels != "lds"
-    path = paths["serial" if args.serial else "pipelined"]
+    # three implementations of the same step: "pipelined2" = software pipeline with consecutive encoder launches
+    # overlapping on two streams, "pipelined1" = the round-2 form (one encoder stream), "serial"
+    paths = {}
+    if not args.serial:
+        if args.enc_streams in (0, 2):
+            paths["pipelined2"] = make_path(True, 2)
+        if args.enc_streams in (0, 1):
+            paths["pipelined1"] = make_path(True, 1)
+    if not args.pipelined:
+        paths["serial"] = make_path(False)
+    for name_, p_ in paths.items():
+        p_.coresident_gnn = name_ != "serial" and args.gnn_kernels != "lds"
+    path = next(iter(paths.values()))
 
     def sync():
         path.synchronize()                                  # both pipeline streams drained into the current one
@@ -277,7 +288,7 @@ def main():
         nonlocal path
         path = paths[name]
         # LDS-free GNN kernels only where they co-run with a resident encoder grid
-        inner_gnn.coresident = (name == "pipelined") if args.gnn_kernels == "auto" else (args.gnn_kernels == "direct")
+        inner_gnn.coresident = (name != "serial") if args.gnn_kernels == "auto" else (args.gnn_kernels == "direct")
 
     SPINUP_STEPS = 40    # untimed device spin-up (clock ramp, TLB/first touch): ~16 ms, part of setup
     calib = None
@@ -296,8 +307,8 @@ def main():
             for _ in range(max(SPINUP_STEPS - args.warmup, 1)):
                 path.step((pts, off), inputs_ready=True)
             sync()
-        if args.serial or args.pipelined:
-            use("serial" if args.serial else "pipelined")
+        if len(paths) == 1:
+            use(next(iter(paths)))
         else:
             calib = {}
             for rnd in range(2):
@@ -309,36 +320,48 @@ def main():
                         path.step((pts, off), inputs_ready=True)
                     sync()
                     calib[name] = min(calib.get(name, 1e9), (time.perf_counter() - tc) / CALIB_STEPS)
-            tcal = torch.tensor([calib["pipelined"], calib["serial"]], dtype=torch.float64, device=dev)
+            names = list(paths)
+            tcal = torch.tensor([calib[n_] for n_ in names], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(tcal, op=dist.ReduceOp.MAX)
-            calib = {"pipelined_ms_per_step": float(tcal[0]) * 1e3, "serial_ms_per_step": float(tcal[1]) * 1e3,
-                     "steps_each": 2 * CALIB_STEPS}
-            use("pipelined" if float(tcal[0]) <= float(tcal[1]) else "serial")
-        chosen = "pipelined" if path is paths["pipelined"] else "serial"
+            calib = {f"{n_}_ms_per_step": float(tcal[i_]) * 1e3 for i_, n_ in enumerate(names)}
+            calib["steps_each"] = 2 * CALIB_STEPS
+            use(names[int(torch.argmin(tcal))])
+        chosen = [n_ for n_, p_ in paths.items() if p_ is path][0]
         for _ in range(args.warmup):                        # the W untimed warmup steps of the contract
             path.step((pts, off), inputs_ready=True)
         sync()                                              # barrier + synchronize: microseconds of idle, no more
         t0 = time.perf_counter()
         for k in range(args.steps):
-            # the encoder kernel is bracketed by HIP events on the stream it is launched on -> live per-launch
-            # duration for the roofline object.  Every EV_EVERY-th launch is bracketed: a pair of timing events costs the
-            # stream ~5.4 us of idle per bracketed launch (kernel traces of the same step with every launch / no launch
-            # timed, round 2: 12.7 vs 7.3 us between two encoder launches, period 335.3 vs 329.0 us).
-            desc_all, emb = path.step((pts, off), encoder_events=ev[k] if k % args.ev_every == 0 else None, inputs_ready=True)
+            # HIP events on the stream the encoder kernel is launched on -> live figures for the roofline object: the END
+            # of every launch is time-stamped (the completion event the GNN stream waits on anyway; launch period =
+            # time between consecutive completions), every EV_EVERY-th launch also gets a start stamp (per-launch
+            # duration; a start + end pair costs its stream ~5 us of idle, kernel traces of round 2).
+            desc_all, emb = path.step((pts, off), encoder_events=(ev[k][0] if k % args.ev_every == 0 else None, ev[k][1]),
+                                      inputs_ready=True)
         t_issue = time.perf_counter() - t0                  # host side only: all K steps enqueued
         sync()
         dt = time.perf_counter() - t0
         gc.enable()
-        if chosen == "pipelined":
+        if chosen != "serial":
             desc_local = desc_all[rank * n_local:(rank + 1) * n_local] if world > 1 else desc_all
-        # outside the timed region: the same kernel alone on the device (no GNN co-running), for reference
+        # outside the timed region: the same kernel alone on the device (no GNN co-running), for reference --
+        # (a) one launch at a time on one stream, (b) consecutive launches overlapping on two streams
         for a, b in solo:
             a.record()
             enc.encode_points_batch((pts, off), out=scratch)
             b.record()
         torch.cuda.synchronize(dev)
         solo_ms = float(np.mean([a.elapsed_time(b) for a, b in solo]))
+        s2 = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        scratch2 = [scratch, torch.empty_like(scratch)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(24)]
+        for j, e in enumerate(ends):
+            with torch.cuda.stream(s2[j % 2]):
+                enc.encode_points_batch((pts, off), out=scratch2[j % 2])
+                e.record(s2[j % 2])
+        torch.cuda.synchronize(dev)
+        solo_period_ms = ends[3].elapsed_time(ends[-1]) / (len(ends) - 4)
         extras = {}
         if rank == 0 and world == 1 and not args.no_extras:
             extras = measure_extras(enc, model, dev, n_local, scratch, (pts, off))
@@ -347,10 +370,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[::args.ev_every]]))
+    # launch period in the timed region: completion to completion, averaged (the first launch's end is the origin)
+    period_ms = ev[0][1].elapsed_time(ev[-1][1]) / (args.steps - 1) if args.steps > 1 else enc_ms
+    overlapped = chosen == "pipelined2"
 
     if rank == 0:
         value = n_total * args.steps / dt
-        achieved = n_local * BYTES_PER_CLOUD / (enc_ms * 1e-3) / 1e9
+        # Launches that overlap (pipelined2) have no meaningful per-launch duration -- two are resident at a time, each
+        # takes about two periods -- so the roofline figure is defined on the launch PERIOD there: algorithmic bytes of
+        # one launch / time between consecutive launch completions.  One launch at a time: bytes / launch duration.
+        roof_ms = period_ms if overlapped else enc_ms
+        achieved = n_local * BYTES_PER_CLOUD / (roof_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "encoder_traffic.json")
         if os.path.exists(tpath):
@@ -363,7 +393,8 @@ def main():
             "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,
-            "step_path": chosen, "calibration": calib,
+            "step_path": "serial" if chosen == "serial" else "pipelined",
+            "encoder_streams": {"pipelined2": 2, "pipelined1": 1}.get(chosen, 1), "calibration": calib,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
             "config": {
@@ -379,10 +410,19 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "encode_fast_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "launch_ms": enc_ms, "launches_timed": len(ev[::args.ev_every]),
-                "co_running": None if chosen == "serial" else "GNN forward of the previous batch on a second stream",
+                "achieved_defined_on": ("launch period: algorithmic bytes of one launch / time between consecutive launch "
+                                        "completions in the timed region (consecutive launches overlap on two streams, two "
+                                        "are resident at a time)" if overlapped else
+                                        "launch duration: algorithmic bytes of one launch / HIP-event time around the launch"),
+                "traffic": traffic,
+                "traffic_source": "profiles/encoder_traffic.json (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 run; not a same-run counter)",
+                "launch_period_ms": period_ms, "launch_ms": enc_ms, "launches_timed": len(ev[::args.ev_every]),
+                "co_running": None if chosen == "serial" else "GNN forward of the previous batch on a second stream"
+                              + ("; the next encoder launch on a second encoder stream" if overlapped else ""),
                 "standalone_launch_ms": solo_ms,
                 "standalone_frac": n_local * BYTES_PER_CLOUD / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "standalone_overlapped_period_ms": solo_period_ms,
+                "standalone_overlapped_frac": n_local * BYTES_PER_CLOUD / (solo_period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": n_local * BYTES_PER_CLOUD,
             },
         }

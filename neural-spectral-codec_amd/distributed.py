@@ -94,18 +94,24 @@ class ShardedDescriptorPath:
     (3.3 MB per rank at 1 024 keyframes) is issued asynchronously and overlaps the GNN forward, and the
     step waits for it at the end (the gathered matrix is what stage-1 retrieval consumes).
 
-    ``pipeline=True`` software-pipelines consecutive steps on two HIP streams: the encoder of batch k+1 is
-    issued on its own stream right behind the encoder of batch k, and the exchange + GNN of batch k run on a
-    second stream under it (results stay valid for ``_PIPE_BUFFERS - 1`` further steps).  The encoder grid is fully resident (4 workgroups per CU take 157.6 of the
-    160 KB of LDS and 448 of the 512 VGPRs of a SIMD lane), so the GNN is launched in its LDS-free,
-    < 64-VGPR form (``gnn.coresident``, NSC_GAT_CORESIDENT) whose workgroups fit in what is left.  Descriptor
-    buffers are double-buffered; ``step`` returns without waiting and its results are valid after
-    ``synchronize()`` (or once the caller's stream has waited on ``last_event``)."""
+    ``pipeline=True`` software-pipelines consecutive steps on HIP streams of their own: the encoder of batch k+1 is
+    issued without waiting for batch k, and the exchange + GNN of batch k run on a second stream under it (results stay
+    valid for ``_PIPE_BUFFERS - 1`` further steps).  ``encoder_streams=2`` (the default) alternates consecutive encoder
+    launches over TWO streams, so that they overlap: while the four workgroups per CU of launch k drain through their
+    finish phase, workgroups of launch k+1 already stream (the finish of one launch, its launch ramp and the completion
+    marker of its stream hide under the streaming of the next).  The resident grid is then up to five encoder
+    workgroups per CU -- 5 x 27.9 KB of the 160 KB of LDS, 5 x 80 of the 512 VGPRs of a SIMD lane -- so the GNN is
+    launched in its LDS-free, <= 56-VGPR form (``gnn.coresident``, NSC_GAT_CORESIDENT), two waves of which fit in the
+    112 registers left (tests/test_abi_cpu.py::test_coresident_register_budget).  Descriptor buffers rotate;
+    ``step`` returns without waiting and its results are valid after ``synchronize()`` (or once the caller's stream
+    has waited on ``last_event``)."""
 
     def __init__(self, encoder, gnn, n_total: int, poses=None, temporal_neighbors: int = 5,
-                 n_layers: int = 3, group=None, overlap: bool = True, pipeline: bool = False):
+                 n_layers: int = 3, group=None, overlap: bool = True, pipeline: bool = False,
+                 encoder_streams: int = 2):
         self.encoder, self.gnn, self.group = encoder, gnn, group
         self.pipeline = pipeline
+        self.encoder_streams = max(1, int(encoder_streams))
         self.coresident_gnn = True         # pipeline mode: launch the GNN in its NSC_GAT_CORESIDENT form
         self._k = 0
         self._streams = None
@@ -145,21 +151,22 @@ class ShardedDescriptorPath:
 
     def _pipe_setup(self, device):
         inner = getattr(self.gnn, "gnn", self.gnn)
-        if hasattr(inner, "coresident") and self.coresident_gnn:
-            inner.coresident = True
+        if hasattr(inner, "coresident"):
+            inner.coresident = bool(self.coresident_gnn)     # the kernel set this path asked for, whatever was set before
         n_local, d = self.hi - self.lo, int(getattr(self.encoder, "output_dim", 800))
         nb = self._PIPE_BUFFERS
         if device.type == "cuda":
-            sE, sG = torch.cuda.Stream(device), torch.cuda.Stream(device)
+            sE = [torch.cuda.Stream(device) for _ in range(self.encoder_streams)]
+            sG = torch.cuda.Stream(device)
             cur = torch.cuda.current_stream(device)
-            sE.wait_stream(cur)
-            sG.wait_stream(cur)
+            for st in sE + [sG]:
+                st.wait_stream(cur)
             self._ev_enc = [torch.cuda.Event() for _ in range(nb)]
             self._ev_gnn = [torch.cuda.Event() for _ in range(nb)]
         else:
             # host tensors (the gloo tests of the buffer rotation and the exchange): no streams, every launch is
             # synchronous, so the same issue order runs as a plain sequence
-            sE = sG = None
+            sE, sG = None, None
             self._ev_enc = self._ev_gnn = [None] * nb
         self._streams = (sE, sG)
         self._desc = [torch.empty((n_local, d), dtype=torch.float32, device=device) for _ in range(nb)]
@@ -168,14 +175,15 @@ class ShardedDescriptorPath:
         device = torch.device(self.encoder.alpha.device)
         if self._streams is None:
             self._pipe_setup(device)
-        sE, sG = self._streams
+        sEs, sG = self._streams
         nb = self._PIPE_BUFFERS
         i = self._k % nb
-        if sE is None:
+        if sEs is None:
             local = self.encoder.encode_points_batch(clouds, out=self._desc[i])
             res = self._exchange_and_enhance(local)
             self._k += 1
             return res
+        sE = sEs[self._k % len(sEs)]                          # consecutive launches alternate over the encoder streams
         caller = torch.cuda.current_stream(device)
         if not inputs_ready:
             # the clouds may still be being written on the caller's stream: order the encoder behind it
@@ -186,7 +194,7 @@ class ShardedDescriptorPath:
             # cross-stream barrier packet (each one costs ~20 us of idle between two encoder launches).
             if self._k >= nb and not self._ev_gnn[i].query():
                 sE.wait_event(self._ev_gnn[i])
-            if encoder_events is not None:
+            if encoder_events is not None and encoder_events[0] is not None:
                 encoder_events[0].record(sE)
             local = self.encoder.encode_points_batch(clouds, out=self._desc[i])
             done = encoder_events[1] if encoder_events is not None else self._ev_enc[i]
@@ -208,20 +216,22 @@ class ShardedDescriptorPath:
     def synchronize(self):
         """Make the caller's current stream wait for every step issued so far (pipeline mode)."""
         if self._streams is not None and self._streams[0] is not None:
-            cur = torch.cuda.current_stream(self._streams[0].device)
-            cur.wait_stream(self._streams[0])
+            cur = torch.cuda.current_stream(self._streams[1].device)
+            for st in self._streams[0]:
+                cur.wait_stream(st)
             cur.wait_stream(self._streams[1])
 
     def step(self, clouds, encoder_events=None, inputs_ready: bool = False):
         """clouds: this rank's shard (list of arrays or (points, offsets) device tensors).
         Returns (all descriptors (n_total, D), enhanced embeddings of the owned rows (hi-lo, D)).
-        ``encoder_events``: optional (start, end) torch.cuda.Event pair recorded around the encoder launch.
+        ``encoder_events``: optional (start, end) torch.cuda.Event pair recorded around the encoder launch on the stream
+        it is issued on (start may be None: only the completion of the launch is time-stamped).
         ``inputs_ready`` (pipeline mode): the clouds are already complete in HBM (nothing pending on the caller's
         stream writes them), so the encoder stream does not have to wait for the caller's stream -- that
         cross-stream wait costs ~10 us of idle between two encoder launches."""
         if self.pipeline:
             return self._step_pipelined(clouds, encoder_events, inputs_ready)
-        if encoder_events is not None:
+        if encoder_events is not None and encoder_events[0] is not None:
             encoder_events[0].record()
         local = self.encoder.encode_points_batch(clouds)
         if encoder_events is not None:

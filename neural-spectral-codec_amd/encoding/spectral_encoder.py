@@ -54,7 +54,9 @@ def _default_lut(device):
 def _workspace(device, nbytes):
     if nbytes == 0:
         return None
-    key = str(device)
+    # one scratch buffer per (device, stream): launches issued on different streams may overlap (the pipelined step
+    # alternates its encoder launches over two streams), launches on one stream are ordered
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

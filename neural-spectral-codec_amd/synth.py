@@ -5,7 +5,7 @@ produces (src/data/kitti_loader.py:113, nclt_loader.py:230-253, helipr_loader.py
 """
 import numpy as np
 
-__all__ = ["make_cloud", "make_clouds_packed", "make_clouds_device", "make_pose_chain"]
+__all__ = ["make_cloud", "make_clouds_packed", "make_clouds_device", "make_pose_chain", "randomize_bn_stats"]
 
 
 def _sph_to_xyz(az, el, r):
@@ -167,3 +167,17 @@ def make_pose_chain(n, seed=0):
     poses[:, 1, 3] = xy[:, 1]
     poses[:, 2, 3] = rng.normal(0.0, 0.05, n)
     return poses
+
+
+def randomize_bn_stats(model, seed=1):
+    """Give every BatchNorm of a freshly initialised model non-trivial running stats and affine terms (fresh modules
+    have 0 / 1, which would make eval-mode BatchNorm a no-op in benchmarks and parity tests alike)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                m.running_mean.copy_((torch.randn(m.num_features, generator=g) * 0.1).to(m.running_mean.device))
+                m.running_var.copy_((torch.rand(m.num_features, generator=g) * 1.5 + 0.25).to(m.running_var.device))
+                m.weight.copy_((torch.rand(m.num_features, generator=g) + 0.5).to(m.weight.device))
+                m.bias.copy_((torch.randn(m.num_features, generator=g) * 0.1).to(m.bias.device))

@@ -59,6 +59,23 @@ def usable_cores():
     return max(1, n)
 
 
+def read_clocks():
+    """Diagnostic (NSC_BENCH_CLOCKS=1): the active DPM levels and the power reading of card 0 from sysfs."""
+    import glob
+    out = {}
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_*")) + sorted(
+            glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_*")) + sorted(
+            glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq*_input")):
+        try:
+            txt = open(f).read().strip()
+        except OSError:
+            continue
+        key = "/".join(f.split("/")[4:5] + f.split("/")[-1:])
+        act = [ln for ln in txt.splitlines() if ln.endswith("*")]
+        out[key] = act[0] if act else txt[:60]
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -203,6 +220,7 @@ def main():
     ap.add_argument("--pipelined", action="store_true", help=argparse.SUPPRESS)   # force the software-pipelined path
     # consecutive encoder launches alternate over this many streams (2: they overlap); 0 = let the calibration choose
     ap.add_argument("--enc-streams", type=int, default=0, choices=[0, 1, 2], help=argparse.SUPPRESS)
+    ap.add_argument("--one-batch", action="store_true", help=argparse.SUPPRESS)      # every step reads the same batch
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -241,6 +259,20 @@ def main():
     synth.randomize_bn_stats(model)
     model = model.to(dev).eval()
     pts, off = synth.make_clouds_device(n_local, N_POINTS, dev, seed=1234 + rank)
+    # Consecutive steps read DIFFERENT batches (two resident sets of n_local clouds, alternating): launches of
+    # consecutive steps overlap on the device, and two launches streaming the same 1.97 GB could meet each other's
+    # lines in the 256 MB Infinity Cache -- bytes that would not have come from HBM.  --one-batch restores round 2's
+    # single resident batch.
+    batches = [(pts, off)]
+    if not args.one_batch:
+        batches.append(synth.make_clouds_device(n_local, N_POINTS, dev, seed=99991 + rank))
+    nbat = len(batches)
+    step_no = [0]
+
+    def next_batch():
+        b = batches[step_no[0] % nbat]
+        step_no[0] += 1
+        return b
     poses = synth.make_pose_chain(n_total, 0)
     # Two implementations of the same step: "pipelined" = consecutive steps software-pipelined
     # on two HIP streams (encoder of batch k+1 over the exchange + GNN of batch k), "serial" = one stream.  Every
@@ -305,31 +337,33 @@ def main():
         for name in paths:                                  # the first step also builds the cached graph
             use(name)
             for _ in range(max(SPINUP_STEPS - args.warmup, 1)):
-                path.step((pts, off), inputs_ready=True)
+                path.step(next_batch(), inputs_ready=True)
             sync()
         if len(paths) == 1:
             use(next(iter(paths)))
         else:
-            calib = {}
+            calib, calib_all = {}, {}
             for rnd in range(2):
                 for name in paths:
                     use(name)
                     sync()
                     tc = time.perf_counter()
                     for _ in range(CALIB_STEPS):
-                        path.step((pts, off), inputs_ready=True)
+                        path.step(next_batch(), inputs_ready=True)
                     sync()
                     calib[name] = min(calib.get(name, 1e9), (time.perf_counter() - tc) / CALIB_STEPS)
+                    calib_all.setdefault(name, []).append(round((time.perf_counter() - tc) / CALIB_STEPS * 1e3, 4))
             names = list(paths)
             tcal = torch.tensor([calib[n_] for n_ in names], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(tcal, op=dist.ReduceOp.MAX)
             calib = {f"{n_}_ms_per_step": float(tcal[i_]) * 1e3 for i_, n_ in enumerate(names)}
             calib["steps_each"] = 2 * CALIB_STEPS
+            calib["rounds_ms_per_step_rank0"] = calib_all
             use(names[int(torch.argmin(tcal))])
         chosen = [n_ for n_, p_ in paths.items() if p_ is path][0]
         for _ in range(args.warmup):                        # the W untimed warmup steps of the contract
-            path.step((pts, off), inputs_ready=True)
+            path.step(next_batch(), inputs_ready=True)
         sync()                                              # barrier + synchronize: microseconds of idle, no more
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -337,9 +371,11 @@ def main():
             # of every launch is time-stamped (the completion event the GNN stream waits on anyway; launch period =
             # time between consecutive completions), every EV_EVERY-th launch also gets a start stamp (per-launch
             # duration; a start + end pair costs its stream ~5 us of idle, kernel traces of round 2).
-            desc_all, emb = path.step((pts, off), encoder_events=(ev[k][0] if k % args.ev_every == 0 else None, ev[k][1]),
+            last_batch = next_batch()
+            desc_all, emb = path.step(last_batch, encoder_events=(ev[k][0] if k % args.ev_every == 0 else None, ev[k][1]),
                                       inputs_ready=True)
         t_issue = time.perf_counter() - t0                  # host side only: all K steps enqueued
+        clocks_busy = read_clocks() if os.environ.get("NSC_BENCH_CLOCKS") == "1" else None   # device still mid-run
         sync()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -358,7 +394,7 @@ def main():
         ends = [torch.cuda.Event(enable_timing=True) for _ in range(24)]
         for j, e in enumerate(ends):
             with torch.cuda.stream(s2[j % 2]):
-                enc.encode_points_batch((pts, off), out=scratch2[j % 2])
+                enc.encode_points_batch(batches[j % nbat], out=scratch2[j % 2])
                 e.record(s2[j % 2])
         torch.cuda.synchronize(dev)
         solo_period_ms = ends[3].elapsed_time(ends[-1]) / (len(ends) - 4)
@@ -393,6 +429,15 @@ def main():
             "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,
+            "clocks_mid_run": clocks_busy,
+            "stream_debug": {"hw_queue_classes": getattr(path, "queue_classes", None),
+                             "encoder_waits_for_gnn": getattr(path, "gnn_waits", None),
+                             "launch_end_intervals_us": [round(ev[k][1].elapsed_time(ev[k + 1][1]) * 1e3, 1)
+                                                         for k in range(min(args.steps, 64) - 1)],
+                             # --ev-every 1: (start, end) of every launch relative to the first start
+                             "launch_windows_us": ([(round(ev[0][0].elapsed_time(ev[k][0]) * 1e3, 1),
+                                                     round(ev[0][0].elapsed_time(ev[k][1]) * 1e3, 1))
+                                                    for k in range(min(args.steps, 64))] if args.ev_every == 1 else None)},
             "step_path": "serial" if chosen == "serial" else "pipelined",
             "encoder_streams": {"pipelined2": 2, "pipelined1": 1}.get(chosen, 1), "calibration": calib,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -431,7 +476,7 @@ def main():
             # the headline workload is the uniform-order batch; the same kernel alone on sensor-ordered clouds:
             line["roofline"]["standalone_launch_ms_by_input_order"] = dict(extras["encoder_input_order_ms"])
         if world == 1 and not args.no_cpu_baseline:
-            cb, odesc = cpu_baseline(pts, off, model, min(args.cpu_sample, n_local))
+            cb, odesc = cpu_baseline(last_batch[0], last_batch[1], model, min(args.cpu_sample, n_local))   # the batch of the last step
             line["cpu_baseline"] = cb
             # parity gate next to the number: sample of this run's descriptors vs the oracle
             got = desc_local[: odesc.shape[0]].cpu().numpy()

@@ -83,6 +83,76 @@ def shard_graph(desc_all: torch.Tensor, lo: int, hi: int, poses=None, n_layers: 
     return g, lo - wlo
 
 
+def hw_queue_classes(streams, spin_cycles: int = 250_000):
+    """Which of ``streams`` share a hardware queue?  HIP multiplexes its streams over a few HSA queues
+    (GPU_MAX_HW_QUEUES, 4 by default), and which streams end up together depends on the addresses the runtime's queues
+    happen to get -- it differs from process to process.  Two streams on one queue execute in order: launches issued
+    on them cannot overlap.  Probe (setup only, a few milliseconds): a one-thread spin kernel on each of two streams --
+    distinct queues run them side by side, a shared queue one after the other.  Returns a class id per stream (equal
+    ids share a queue), or None when the spin kernel is not available."""
+    import time
+    if not streams or not hasattr(torch.cuda, "_sleep"):
+        return None
+    dev = streams[0].device
+
+    def timed(idx):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in idx:
+            with torch.cuda.stream(streams[i]):
+                torch.cuda._sleep(spin_cycles)
+                torch.cuda._sleep(spin_cycles)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    for i in range(len(streams)):
+        timed([i])                                            # first use of a stream binds its queue
+    one = min(timed([0]) for _ in range(3))
+    reps, cls = [], []
+    for i in range(len(streams)):
+        found = None
+        for r in reps:
+            if min(timed([r, i]), timed([r, i])) > 1.6 * one:
+                found = cls[r]
+                break
+        if found is None:
+            found = len(reps)
+            reps.append(i)
+        cls.append(found)
+    return cls
+
+
+def concurrent_streams(device, n: int, candidates: int = 12):
+    """``n`` streams that sit on ``n`` different hardware queues (see hw_queue_classes), none of them the queue of the
+    caller's current stream when that can be had.  Falls back to plain new streams when the probe is unavailable or the
+    device has fewer queues than asked for.  All at the default priority: a high-priority encoder (or GNN) stream was
+    measured 40-60 % slower per step (round 3: the other side starves and the buffer rotation stalls)."""
+    cur = torch.cuda.current_stream(device)
+    pool = [torch.cuda.Stream(device) for _ in range(candidates)]
+    cls = hw_queue_classes([cur] + pool)
+    if cls is None:
+        return pool[:n], None
+    picked, used = [], {cls[0]}
+    for st, c in zip(pool, cls[1:]):
+        if c not in used:
+            picked.append(st)
+            used.add(c)
+        if len(picked) == n:
+            break
+    if len(picked) < n:                                       # not enough queues beside the caller's: share the caller's
+        for st, c in zip(pool, cls[1:]):
+            if st not in picked and c not in {cls[1 + pool.index(q)] for q in picked}:
+                picked.append(st)
+            if len(picked) == n:
+                break
+    for st in pool:                                           # still short: whatever is left
+        if len(picked) == n:
+            break
+        if st not in picked:
+            picked.append(st)
+    return picked, {"caller": cls[0], "picked": [cls[1 + pool.index(q)] for q in picked], "queues_seen": len(set(cls))}
+
+
 class ShardedDescriptorPath:
     """encode (local shard) -> all-gather descriptors -> GNN on shard + halo (local rows out).
 
@@ -115,6 +185,8 @@ class ShardedDescriptorPath:
         self.coresident_gnn = True         # pipeline mode: launch the GNN in its NSC_GAT_CORESIDENT form
         self._k = 0
         self._streams = None
+        self.queue_classes = None          # hardware-queue classes of the pipeline's streams (set with the streams)
+        self.gnn_waits = 0                 # times the encoder stream had to wait for a GNN pass (buffer still being read)
         self.last_event = None
         self.n_total, self.poses = n_total, poses
         self.M, self.L = temporal_neighbors, n_layers
@@ -156,8 +228,9 @@ class ShardedDescriptorPath:
         n_local, d = self.hi - self.lo, int(getattr(self.encoder, "output_dim", 800))
         nb = self._PIPE_BUFFERS
         if device.type == "cuda":
-            sE = [torch.cuda.Stream(device) for _ in range(self.encoder_streams)]
-            sG = torch.cuda.Stream(device)
+            # the encoder streams must be able to run side by side, and the GNN beside them: one hardware queue each
+            sts, self.queue_classes = concurrent_streams(device, self.encoder_streams + 1)
+            sE, sG = sts[:self.encoder_streams], sts[self.encoder_streams]
             cur = torch.cuda.current_stream(device)
             for st in sE + [sG]:
                 st.wait_stream(cur)
@@ -194,6 +267,7 @@ class ShardedDescriptorPath:
             # cross-stream barrier packet (each one costs ~20 us of idle between two encoder launches).
             if self._k >= nb and not self._ev_gnn[i].query():
                 sE.wait_event(self._ev_gnn[i])
+                self.gnn_waits += 1
             if encoder_events is not None and encoder_events[0] is not None:
                 encoder_events[0].record(sE)
             local = self.encoder.encode_points_batch(clouds, out=self._desc[i])

@@ -220,6 +220,8 @@ class ShardedDescriptorPath:
 
     # -- two-stream software pipeline -----------------------------------------------------------
     _PIPE_BUFFERS = 4      # descriptor buffers in rotation: the encoder stream never has to wait for the GNN
+    probe_queues = True    # pick the pipeline's streams on distinct hardware queues (concurrent_streams); a test that
+                           # runs several ranks as threads of one process turns the timing probe off
 
     def _pipe_setup(self, device):
         inner = getattr(self.gnn, "gnn", self.gnn)
@@ -229,7 +231,10 @@ class ShardedDescriptorPath:
         nb = self._PIPE_BUFFERS
         if device.type == "cuda":
             # the encoder streams must be able to run side by side, and the GNN beside them: one hardware queue each
-            sts, self.queue_classes = concurrent_streams(device, self.encoder_streams + 1)
+            if self.probe_queues:
+                sts, self.queue_classes = concurrent_streams(device, self.encoder_streams + 1)
+            else:
+                sts = [torch.cuda.Stream(device) for _ in range(self.encoder_streams + 1)]
             sE, sG = sts[:self.encoder_streams], sts[self.encoder_streams]
             cur = torch.cuda.current_stream(device)
             for st in sE + [sG]:

@@ -19,7 +19,9 @@ _WS = {}
 
 
 def _ws(device, nbytes, tag):
-    key = (str(device), tag)
+    # one scratch buffer per (device, stream, use): work issued on different streams may overlap (pipelined steps,
+    # several ranks of a test sharing one process), work on one stream is ordered
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)

@@ -113,6 +113,51 @@ def test_multi_rank_gloo_matches_single_process(n_total, world, pipeline):
     assert covered == n_total
 
 
+@pytest.mark.parametrize("mode", ["serial", "pipelined"])
+def test_world8_kitti00_layout(tmp_path, mode):
+    """BASELINE configs[3] in its stated shape: 8 contiguous shards of the 4 541-keyframe set (568 x 5 + 567 x 3 rows:
+    the padded all-gather branch, halo windows at 7 interior boundaries), all-gather, halo-sharded GNN, row-sharded
+    stage-1 retrieval -- the product's distributed.py / ShardedTwoStageRetrieval on every rank, the oracle standing in
+    for the kernels.  The ranks are 8 threads of a child process (torch's in-process group; tests/threaded_cpu_worker.py)."""
+    import subprocess
+    import sys
+    n_total, world = 4541, 8
+    out = str(tmp_path / "w8.npz")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "threaded_cpu_worker.py"), str(world), str(n_total), mode, out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    clouds = [synth.make_cloud(1000 + i, 400, "uniform") for i in range(n_total)]
+    desc = np.stack([orc.encode_points(c) for c in clouds])
+    torch.manual_seed(0)
+    model = create_spectral_gnn(edge_dim=2).eval()
+    go.randomize_bn_stats(model)
+    poses = synth.make_pose_chain(n_total, 3)
+    full = gm.build_chain_graph(torch.from_numpy(desc), 5, "cpu", poses)
+    ref = go.forward_reference(model, full).numpy()
+    single = OracleLocalRetriever()
+    pos = poses[:, :3, 3].astype(np.float32)
+    single.add_to_database(desc, pos)
+    qsel = [0, n_total // 3, n_total // 2, n_total - 1]
+    want_idx, want_val = single.query_batch(desc[qsel], 10, pos[qsel], 8.0)
+    want_idx = torch.where(torch.isinf(want_val), torch.full_like(want_idx, -1), want_idx).numpy()
+    covered, sizes = 0, []
+    for rank in range(world):
+        lo, hi = int(z[f"r{rank}_lo"]), int(z[f"r{rank}_hi"])
+        assert (lo, hi) == nd.shard_range(n_total, rank, world)
+        assert int(z[f"r{rank}_overlap"]) == 0                      # ragged shards: no two-phase exchange
+        assert np.array_equal(z[f"r{rank}_desc_all"], desc), rank   # padded all-gather reproduces the full matrix
+        emb = z[f"r{rank}_emb"]
+        assert emb.shape == (hi - lo, 800)
+        assert np.allclose(emb, ref[lo:hi], rtol=1e-5, atol=1e-6), rank      # halo of 6 is exact at every boundary
+        assert np.array_equal(z[f"r{rank}_retr_idx"], want_idx), rank
+        assert np.array_equal(z[f"r{rank}_retr_val"], want_val.numpy()), rank
+        covered += hi - lo
+        sizes.append(hi - lo)
+    assert covered == n_total and sizes == [568] * 5 + [567] * 3
+
+
 def test_shard_ranges_and_halo():
     assert [nd.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert [nd.shard_range(4541, r, 8)[1] - nd.shard_range(4541, r, 8)[0] for r in range(8)] == [568] * 5 + [567] * 3

@@ -19,6 +19,7 @@
 //                        the NSC_GAT_CORESIDENT set: no LDS, < 64 VGPRs, bit-identical output -- fits beside a
 //                        resident encoder grid so that the GNN of batch k runs under the encoder of batch k+1
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -771,6 +772,24 @@ void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const
     // 64 x 64 tiles with 32 x 32 wave tiles (a third less LDS traffic per FLOP) where they still give two workgroups to
     // every CU (70 KB of LDS each): output_proj at M = 4 541 (923 tiles); input_proj and lin there have 284 / 355
     bool four = w4 >= 512 && !coresident;
+    if (four) {
+        // The 64 x 64 form takes 69.6 KB of dynamic LDS: above 64 KB a kernel has to be opted in, and the attribute is
+        // per DEVICE.  State: one atomic per (instantiation, device) -- 0 not tried, 1 opted in, 2 refused (then the
+        // 32-row tiles run: same results, bit for bit).  Racing threads at worst both set the attribute (idempotent).
+        static std::atomic<int> opted[16];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+            four = false;
+        } else {
+            int s = opted[dev].load(std::memory_order_acquire);
+            if (s == 0) {
+                s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_kernel<2, EPI, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess ? 1 : 2;
+                opted[dev].store(s, std::memory_order_release);
+            }
+            if (s != 1) four = false;
+        }
+    }
     unsigned pad = 0;
 #ifdef NSC_DEV_TUNING
     const int force = gat_tune_env("NSC_TUNE_GEMM_ACC", 0);
@@ -793,12 +812,6 @@ void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const
         hipLaunchKernelGGL((gemm_nt_direct_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N,
                            n_main, K, C, ldc, ep);
     } else if (four) {
-        static bool opted = false;          // dynamic LDS above 64 KB is opted into once per kernel
-        if (!opted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_kernel<2, EPI, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            opted = true;
-        }
         hipLaunchKernelGGL((gemm_nt_kernel<2, EPI, 2>), grid, dim3(256), lds, st, A, lda, B, ldb, Bx, M, N, n_main,
                            K, C, ldc, ep);
     } else {

@@ -6,6 +6,7 @@ csrc/nsc_encoder.hip through the C ABI (include/nsc.h).  The module must live on
 
 Additive API (not in the reference): ``encode_points_batch`` for packed batches of clouds.
 """
+import threading
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -55,8 +56,9 @@ def _workspace(device, nbytes):
     if nbytes == 0:
         return None
     # one scratch buffer per (device, stream): launches issued on different streams may overlap (the pipelined step
-    # alternates its encoder launches over two streams), launches on one stream are ordered
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    # alternates its encoder launches over two streams), launches on one stream are ordered -- unless two host
+    # threads issue on it, hence the thread in the key
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -9,6 +9,8 @@ The module must live on a HIP device; there is no CPU fallback.
 import ctypes as C
 from typing import Optional
 
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -21,7 +23,9 @@ _WS = {}
 def _ws(device, nbytes, tag):
     # one scratch buffer per (device, stream, use): work issued on different streams may overlap (pipelined steps,
     # several ranks of a test sharing one process), work on one stream is ordered
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
+    # ... and per host thread: two threads issuing on one stream interleave their launches (a rehearsal of several ranks
+    # in one process; round 3: two ranks building their CSR in one shared scratch faulted the aggregate kernel)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)

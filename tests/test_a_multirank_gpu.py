@@ -205,9 +205,15 @@ def test_data_parallel_train_step_through_hip_kernels(tmp_path):
     assert len(keys) >= 20
     gscale = max(np.abs(one["g:" + k]).max() for k in keys)
     worst = 0.0
+    # exactly-zero gradients (float32 noise on both sides): a bias in front of a batch-statistics BatchNorm; and, because
+    # the triplet gradient sums to zero over the rows, output_proj.bias and the last BatchNorm's bias
+    zero = {"input_proj.bias", "output_proj.bias", "batch_norms.2.bias"} | {f"convs.{l}.bias" for l in range(3)}
     for k in keys:
         a, b0, b1 = one["g:" + k], two[0]["g:" + k], two[1]["g:" + k]
         assert np.array_equal(b0, b1), f"{k}: the ranks disagree after the all-reduce"
+        if k in zero:
+            assert np.abs(a).max() < 1e-3 * gscale and np.abs(b0).max() < 1e-3 * gscale, k
+            continue
         # float32 sums of the same terms in a different grouping: relative to the layer's own gradient scale
         d = np.abs(a.astype(np.float64) - b0).max() / max(np.abs(a).max(), 1e-6 * gscale)
         worst = max(worst, d)

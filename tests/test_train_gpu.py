@@ -59,7 +59,9 @@ def test_forward_train_and_gradients(n, edge_dim):
     emb = m(g)
     loss = crit.forward_indexed(emb, trip[:, 0], trip[:, 1], trip[:, 2]) + (emb * R.cuda()).sum()
     loss.backward()
-    assert _rel(emb.detach().cpu(), emb_ref) < 1e-4
+    # north_star bar, element-wise (|gpu - ref| <= 1e-4 |ref| + 1e-6), against the float64 evaluation of the restatement
+    emb64 = go.reference_gradients(m, g, lambda e: (e * 0).sum(), dtype=torch.float64)[0]
+    go.assert_within_bar(emb.detach(), emb64, what=f"train-mode forward, {n} nodes")
     assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 1e-6
     params = dict(m.gnn.named_parameters())
     gscale = max(v.abs().max().item() for v in grads_ref.values())
@@ -104,7 +106,8 @@ def test_residual_variants_train(in_dim, out_dim, residual):
     g.x.requires_grad_(True)
     emb = m(g)
     ((emb * R.cuda()).sum() + (emb * emb).sum()).backward()
-    assert _rel(emb.detach().cpu(), emb_ref) < 1e-4
+    emb64 = go.reference_gradients(m, g, lambda e: (e * 0).sum(), dtype=torch.float64)[0]
+    go.assert_within_bar(emb.detach(), emb64, what="train-mode forward (residual variants)")
     assert _rel(g.x.grad.cpu(), gx_ref) < 2e-3
     params = dict(m.named_parameters())
     keys = _key_map(m) + (["residual_proj.weight", "residual_proj.bias"] if m.residual_proj is not None else [])
@@ -252,10 +255,13 @@ def test_config5_full_size_train_step():
     (hidden_dim=256, margin=0.1, dropout 0 for parity): loss, every parameter gradient, the input gradient and one
     Adam step against torch autograd through the restatement (reference src/gnn/trainer.py:186-221).
 
-    Tolerances: train-mode BatchNorm divides by the batch standard deviation, which amplifies float32 rounding; the
-    restatement is therefore evaluated in float32 (the reference's arithmetic) AND float64, and the kernels have to
-    be as close to the float64 result as 4 x the float32 restatement's own distance from it (floor 2e-3 for
-    gradients -- sums over 4 541 nodes in a different order -- and 1e-4 for the embeddings)."""
+    Tolerances are evidence, not a dial: train-mode BatchNorm divides by the batch standard deviation, which on real
+    descriptors (nearly equal rows) amplifies float32 rounding far beyond the 1e-4 eval bar -- so the restatement is
+    evaluated in float32 (the reference's arithmetic) AND float64, and for every quantity the test prints and checks
+    TWO numbers against the float64 result: the kernels' distance and the float32 restatement's own.  The kernels must
+    be no worse than 1.5 x the float32 restatement (both are float32 evaluations of the same formulas; 1.5 covers the
+    different summation order: wave-tree column sums and MFMA k-order here, sequential / pairwise sums in torch), with
+    a floor of 1e-4 (embeddings) / 2e-3 (gradients: sums over 4 541 nodes) below which neither is resolved."""
     import copy
     from neural_spectral_codec_amd.gnn.triplet_miner import create_triplet_miner
     from neural_spectral_codec_amd.keyframe.graph_manager import build_chain_graph
@@ -300,7 +306,17 @@ def test_config5_full_size_train_step():
     loss.backward()                                               # :213
     assert loss64.item() > 0
     assert abs(loss.item() - loss64.item()) <= 1e-4 * abs(loss64.item()) + 1e-7
-    assert dist(emb.detach().cpu(), emb64) <= max(1e-4, 4 * dist(emb32, emb64))
+    FACTOR = 1.5
+    report = []
+
+    def check(name, got, ref32, ref64, floor):
+        d_gpu, d_f32 = dist(got, ref64), dist(ref32, ref64)
+        report.append((name, d_gpu, d_f32))
+        assert d_gpu <= max(floor, FACTOR * d_f32), (
+            f"{name}: kernels {d_gpu:.3e} from the float64 restatement, the float32 restatement {d_f32:.3e} "
+            f"(allowed {FACTOR} x, floor {floor:g})")
+
+    check("embedding (train-mode forward)", emb.detach().cpu(), emb32, emb64, 1e-4)
     params = dict(m.gnn.named_parameters())
     gscale = max(v.abs().max().item() for v in g64.values())
     # Exactly-zero gradients (float32 noise on both sides): a bias in front of a batch-statistics BatchNorm; and,
@@ -311,8 +327,11 @@ def test_config5_full_size_train_step():
         if k in zero:
             assert got.abs().max().item() < 1e-3 * gscale and g64[k].abs().max().item() < 1e-6 * gscale, k
             continue
-        assert dist(got, g64[k]) <= max(2e-3, 4 * dist(g32[k], g64[k])), (k, dist(got, g64[k]), dist(g32[k], g64[k]))
-    assert dist(graph.x.grad.cpu(), gx64) <= max(2e-3, 4 * dist(gx32, gx64))
+        check("grad " + k, got, g32[k], g64[k], 2e-3)
+    check("grad x", graph.x.grad.cpu(), gx32, gx64, 2e-3)
+    print("\nconfigs[4] full size -- max-norm distance from the float64 restatement: kernels | float32 restatement | ratio")
+    for name, d_gpu, d_f32 in report:
+        print(f"  {name:40s} {d_gpu:.3e} | {d_f32:.3e} | {d_gpu / max(d_f32, 1e-300):.2f}")
     # one Adam step (lr 5e-4, L2 weight decay 1e-5, trainer.py:115-119) on both sides
     before = {k: v.detach().cpu().clone() for k, v in params.items()}
     tr.optimizer.step()

@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256) void mine_kernel(const double *__restrict__ po
     int hard = -1;
     if (p.strategy == 0) {
         float best = INFINITY;
+        int first_nan = -1;
         const float *ca = cdf + (long long)la * D;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int lo = c0 + lane;
@@ -473,20 +474,28 @@ __global__ __launch_bounds__(256) void mine_kernel(const double *__restrict__ po
                 for (int c = lane; c < D; c += 64) s += fabsf(ca[c] - cb[c]);
                 s = wave_sumf(s);
                 if (s < best) { best = s; hard = cand; }
+                if (s != s && first_nan < 0) first_nan = cand;
             }
         }
+        // np.argmin (:346) treats NaN as the minimum and returns its first position: a NaN / garbage descriptor row among
+        // the candidates is what the reference would pick; and +inf distances everywhere leave its first candidate
+        if (first_nan >= 0) hard = first_nan;
+        else if (hard < 0) hard = nth_candidate(n, lane, 0, is_neg);
     }
     if (p.strategy == 2) {
         // semi-hard (:352-357): the candidate at position len // 2 of the candidates sorted by W1.  The distances of
-        // this anchor's candidates go to its row of the workspace (+inf elsewhere); the value of that rank is found
-        // by bisection on the float bits (distances are >= 0: unsigned order == float order), ties resolve to the
-        // smaller index (np.argsort's quicksort leaves the order of exact ties undefined).
-        float *row = ws + (long long)la * n;
+        // this anchor's candidates go to its row of the workspace as BIT PATTERNS compared as unsigned integers:
+        // distances are >= 0, so unsigned order == float order; a NaN distance (NaN / garbage descriptor row) becomes the
+        // canonical quiet NaN 0x7fc00000, above +inf -- np.argsort sorts NaN last too; rows that are no candidates hold
+        // 0xffffffff, above every candidate, so neither the counts nor the final pick can ever land on one.  The value
+        // of rank k is found by bisection on the bits, ties resolve to the smaller index (np.argsort's quicksort leaves
+        // the order of exact ties undefined).
+        unsigned *row = reinterpret_cast<unsigned *>(ws + (long long)la * n);
         const float *ca = cdf + (long long)la * D;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int lo = c0 + lane;
             unsigned long long m = __ballot(lo < n && is_neg(lo));
-            if (lo < n) row[lo] = INFINITY;
+            if (lo < n) row[lo] = 0xffffffffu;
             while (m) {
                 const int b = __ffsll((long long)m) - 1;
                 m &= m - 1;
@@ -494,27 +503,27 @@ __global__ __launch_bounds__(256) void mine_kernel(const double *__restrict__ po
                 float sd = 0.0f;
                 for (int c = lane; c < D; c += 64) sd += fabsf(ca[c] - cb[c]);
                 sd = wave_sumf(sd);
-                if (lane == b) row[c0 + b] = sd;
+                if (lane == b) row[c0 + b] = (sd != sd) ? 0x7fc00000u : __float_as_uint(sd);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the wave re-reads its own row across lanes
         const int k = nneg / 2;
-        unsigned lo_b = 0u, hi_b = 0x7f800000u;                      // smallest v with #(d <= v) >= k + 1
+        unsigned lo_b = 0u, hi_b = 0x7fc00000u;                      // smallest v with #(d <= v) >= k + 1
         while (lo_b < hi_b) {
             const unsigned mid = lo_b + (hi_b - lo_b) / 2u;
             int cnt = 0;
             for (int c0 = 0; c0 < n; c0 += 64) {
                 const int lo = c0 + lane;
-                cnt += __popcll(__ballot(lo < n && __float_as_uint(row[lo]) <= mid));
+                cnt += __popcll(__ballot(lo < n && row[lo] <= mid));
             }
             if (cnt >= k + 1) hi_b = mid; else lo_b = mid + 1u;
         }
         int less = 0;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int lo = c0 + lane;
-            less += __popcll(__ballot(lo < n && __float_as_uint(row[lo]) < lo_b));
+            less += __popcll(__ballot(lo < n && row[lo] < lo_b));
         }
-        hard = nth_candidate(n, lane, k - less, [&](int lo) { return __float_as_uint(row[lo]) == lo_b; });
+        hard = nth_candidate(n, lane, k - less, [&](int lo) { return row[lo] == lo_b; });
     }
     for (int k = 0; k < p.per_anchor; ++k) {           // :211-216
         const int rp = (int)(mine_hash(p.seed, (unsigned)la, 2u * k) % (unsigned)npos);

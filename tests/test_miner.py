@@ -120,3 +120,40 @@ def test_gpu_miner_semi_hard_matches_reference():
         n_diff += n != hard[a][0][1]
     assert n_swapped <= 0.02 * len(got)
     assert n_diff > 0.9 * len(got)                              # it is not the hard negative
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", ["hard", "semi-hard"])
+def test_gpu_miner_with_nan_descriptor_rows(strategy):
+    """A NaN descriptor row makes every W1 distance to it NaN.  The mined negative must still be a CANDIDATE of the
+    anchor (never the anchor itself or a temporal neighbour, which a bisection that lands on the +inf of a
+    non-candidate could return): np.argmin (hard, :346) returns the first NaN candidate, np.argsort (semi-hard,
+    :352-357) sorts NaN last -- the median stays a real candidate while fewer than half of them are NaN."""
+    from neural_spectral_codec_amd.gnn.triplet_miner import TripletMiner
+    idx = np.where(G["seq"] == 0)[0]
+    desc = G["desc"][idx].copy()
+    pos = G["poses"][idx]
+    res = mo.mine_sequence(G["desc"][idx], pos[:, :3, 3])
+    # poison a few rows that are negative candidates of many anchors
+    cnt = np.zeros(len(idx), int)
+    for r in res:
+        if r is not None:
+            cnt[r[1]] += 1
+    bad = np.argsort(-cnt)[:3]
+    desc[bad] = np.nan
+    np.random.seed(6)
+    trip = TripletMiner(mining_strategy=strategy).mine_triplets(desc, pos, 1, None)
+    assert len(trip) == sum(r is not None for r in res)
+    n_nan_pick = 0
+    for a, p, n in trip:
+        cands = res[a][1].tolist()
+        assert n in set(cands), (a, n)                       # a real candidate of this anchor, whatever the NaNs
+        if a in set(bad.tolist()):
+            continue                                         # the anchor's own row is NaN: every distance is NaN
+        nan_c = [c for c in cands if c in set(bad.tolist())]
+        if strategy == "hard" and nan_c:
+            assert n == min(nan_c), (a, n, nan_c)            # np.argmin: the first NaN position
+            n_nan_pick += 1
+        if strategy == "semi-hard" and len(nan_c) * 2 < len(cands) - 1:
+            assert n not in set(bad.tolist()), (a, n)        # NaNs sort last: the median is a finite candidate
+    assert strategy != "hard" or n_nan_pick > 0

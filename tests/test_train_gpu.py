@@ -23,13 +23,21 @@ def _bar_ratio(out, ref64, rtol=1e-4, atol=1e-6):
 
 
 def _assert_train_forward(emb_gpu, emb32, emb64, what):
-    """Train-mode forward, ELEMENT-WISE against the float64 evaluation of the restatement.  Batch-statistics BatchNorm
-    divides by a standard deviation estimated from the rows, which amplifies float32 rounding; where even the float32
-    restatement (the reference's own arithmetic) leaves the 1e-4 |ref| + 1e-6 bar, the kernels may be as far out as
-    1.5 x that (different summation order), no further.  Both figures are printed."""
-    r_gpu, r_f32 = _bar_ratio(emb_gpu, emb64), _bar_ratio(emb32, emb64)
-    print(f"{what}: worst element / bar -- kernels {r_gpu:.2f}, float32 restatement {r_f32:.2f}")
-    assert r_gpu <= max(1.0, 1.5 * r_f32), f"{what}: kernels {r_gpu:.2f} x the bar, float32 restatement {r_f32:.2f} x"
+    """Train-mode forward against the float64 evaluation of the restatement.  Batch-statistics BatchNorm divides by a
+    standard deviation estimated from the rows, which amplifies float32 rounding; the float32 restatement (the
+    reference's own arithmetic) itself leaves the element-wise 1e-4 |ref| + 1e-6 bar on small batches.  So the kernels
+    are held to the float32 restatement's own accuracy, both figures printed:
+      * RMS error no worse than 1.5 x the float32 restatement's (a stable statistic; 1.5 covers the different summation
+        order of two float32 evaluations of the same formulas),
+      * worst element / bar no worse than max(1, 3 x the float32 restatement's) -- the maximum over ~1e5 heavy-tailed
+        ratios (elements near zero have a 1e-6 bound) scatters by about 2 x between two equally accurate evaluations."""
+    g, a, r = emb_gpu.detach().cpu().double(), emb32.detach().cpu().double(), emb64.detach().cpu().double()
+    rms_gpu, rms_f32 = (g - r).pow(2).mean().sqrt().item(), (a - r).pow(2).mean().sqrt().item()
+    w_gpu, w_f32 = _bar_ratio(g, r), _bar_ratio(a, r)
+    print(f"{what}: RMS error kernels {rms_gpu:.3e} / float32 restatement {rms_f32:.3e}; worst element / bar "
+          f"kernels {w_gpu:.2f} / float32 restatement {w_f32:.2f}")
+    assert rms_gpu <= 1.5 * rms_f32 + 1e-9, f"{what}: RMS error {rms_gpu:.3e} vs {rms_f32:.3e} of the float32 restatement"
+    assert w_gpu <= max(1.0, 3.0 * w_f32), f"{what}: worst element {w_gpu:.2f} x the bar, float32 restatement {w_f32:.2f} x"
 
 
 def _setup(n, edge_dim=2, dropout=0.0, seed=0):

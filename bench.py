@@ -343,6 +343,9 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     solo = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     scratch = torch.empty((n_local, 800), dtype=torch.float32, device=dev)
+    # streams of the encoder-alone reference measurement, picked (hardware-queue probe: ~20 ms of an almost idle device)
+    # HERE, before the spin-up -- an idle stretch right before a measurement lets the device drop its clocks
+    s2, _ = nd.concurrent_streams(dev, 2)
     gc.collect()
     gc.disable()                                            # no collector pause on the enqueueing thread
     with torch.no_grad():
@@ -401,9 +404,10 @@ def main():
             b.record()
         torch.cuda.synchronize(dev)
         solo_ms = float(np.mean([a.elapsed_time(b) for a, b in solo]))
-        s2, _ = nd.concurrent_streams(dev, 2)               # two streams on two hardware queues
         scratch2 = [scratch, torch.empty_like(scratch)]
         ends = [torch.cuda.Event(enable_timing=True) for _ in range(24)]
+        for st in s2:
+            st.wait_stream(torch.cuda.current_stream(dev))
         for j, e in enumerate(ends):
             with torch.cuda.stream(s2[j % 2]):
                 enc.encode_points_batch(batches[j % nbat], out=scratch2[j % 2])

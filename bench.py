@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--enc-streams", type=int, default=0, choices=[0, 1, 2], help=argparse.SUPPRESS)
     ap.add_argument("--one-batch", action="store_true", help=argparse.SUPPRESS)      # every step reads the same batch
     ap.add_argument("--calibrate", action="store_true", help=argparse.SUPPRESS)      # time all three step implementations
+    ap.add_argument("--gnn-streams", type=int, default=1, help=argparse.SUPPRESS)    # GNN passes alternate over this many streams
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -290,7 +291,8 @@ def main():
             return enc.encode_points_batch(clouds, out=desc_local)
 
     def make_path(pipelined, enc_streams=1):
-        p_ = nd.ShardedDescriptorPath(enc, model, n_total, poses, pipeline=pipelined, encoder_streams=enc_streams)
+        p_ = nd.ShardedDescriptorPath(enc, model, n_total, poses, pipeline=pipelined, encoder_streams=enc_streams,
+                                      gnn_streams=args.gnn_streams)
         if not pipelined:
             p_.encoder = _Enc
         return p_

@@ -178,10 +178,11 @@ class ShardedDescriptorPath:
 
     def __init__(self, encoder, gnn, n_total: int, poses=None, temporal_neighbors: int = 5,
                  n_layers: int = 3, group=None, overlap: bool = True, pipeline: bool = False,
-                 encoder_streams: int = 2):
+                 encoder_streams: int = 2, gnn_streams: int = 1):
         self.encoder, self.gnn, self.group = encoder, gnn, group
         self.pipeline = pipeline
         self.encoder_streams = max(1, int(encoder_streams))
+        self.gnn_streams = max(1, int(gnn_streams))
         self.coresident_gnn = True         # pipeline mode: launch the GNN in its NSC_GAT_CORESIDENT form
         self._k = 0
         self._streams = None
@@ -193,6 +194,8 @@ class ShardedDescriptorPath:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.lo, self.hi = shard_range(n_total, self.rank, self.world)
+        if self.world > 1:
+            self.gnn_streams = 1           # one communicator: its collectives stay on one stream, in one order on all ranks
         self.halo = n_layers * (temporal_neighbors // 2)
         n_local = self.hi - self.lo
         # pipeline mode hides the whole exchange + GNN under the next encoder: ONE all-gather per step then (every
@@ -231,13 +234,14 @@ class ShardedDescriptorPath:
         nb = self._PIPE_BUFFERS
         if device.type == "cuda":
             # the encoder streams must be able to run side by side, and the GNN beside them: one hardware queue each
+            ns = self.encoder_streams + self.gnn_streams
             if self.probe_queues:
-                sts, self.queue_classes = concurrent_streams(device, self.encoder_streams + 1)
+                sts, self.queue_classes = concurrent_streams(device, ns)
             else:
-                sts = [torch.cuda.Stream(device) for _ in range(self.encoder_streams + 1)]
-            sE, sG = sts[:self.encoder_streams], sts[self.encoder_streams]
+                sts = [torch.cuda.Stream(device) for _ in range(ns)]
+            sE, sG = sts[:self.encoder_streams], sts[self.encoder_streams:]
             cur = torch.cuda.current_stream(device)
-            for st in sE + [sG]:
+            for st in sE + sG:
                 st.wait_stream(cur)
             self._ev_enc = [torch.cuda.Event() for _ in range(nb)]
             self._ev_gnn = [torch.cuda.Event() for _ in range(nb)]
@@ -253,7 +257,7 @@ class ShardedDescriptorPath:
         device = torch.device(self.encoder.alpha.device)
         if self._streams is None:
             self._pipe_setup(device)
-        sEs, sG = self._streams
+        sEs, sGs = self._streams
         nb = self._PIPE_BUFFERS
         i = self._k % nb
         if sEs is None:
@@ -262,6 +266,7 @@ class ShardedDescriptorPath:
             self._k += 1
             return res
         sE = sEs[self._k % len(sEs)]                          # consecutive launches alternate over the encoder streams
+        sG = sGs[self._k % len(sGs)]                          # ... and the exchange + GNN passes over the GNN streams
         caller = torch.cuda.current_stream(device)
         if not inputs_ready:
             # the clouds may still be being written on the caller's stream: order the encoder behind it
@@ -295,10 +300,9 @@ class ShardedDescriptorPath:
     def synchronize(self):
         """Make the caller's current stream wait for every step issued so far (pipeline mode)."""
         if self._streams is not None and self._streams[0] is not None:
-            cur = torch.cuda.current_stream(self._streams[1].device)
-            for st in self._streams[0]:
+            cur = torch.cuda.current_stream(self._streams[0][0].device)
+            for st in list(self._streams[0]) + list(self._streams[1]):
                 cur.wait_stream(st)
-            cur.wait_stream(self._streams[1])
 
     def step(self, clouds, encoder_events=None, inputs_ready: bool = False):
         """clouds: this rank's shard (list of arrays or (points, offsets) device tensors).

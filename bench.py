@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--one-batch", action="store_true", help=argparse.SUPPRESS)      # every step reads the same batch
     ap.add_argument("--calibrate", action="store_true", help=argparse.SUPPRESS)      # time all three step implementations
     ap.add_argument("--gnn-streams", type=int, default=1, help=argparse.SUPPRESS)    # GNN passes alternate over this many streams
+    ap.add_argument("--gnn-graph", type=int, default=0, help=argparse.SUPPRESS)      # 1: replay the GNN forward as a hipGraph
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -292,7 +293,7 @@ def main():
 
     def make_path(pipelined, enc_streams=1):
         p_ = nd.ShardedDescriptorPath(enc, model, n_total, poses, pipeline=pipelined, encoder_streams=enc_streams,
-                                      gnn_streams=args.gnn_streams)
+                                      gnn_streams=args.gnn_streams, gnn_graph=bool(args.gnn_graph))
         if not pipelined:
             p_.encoder = _Enc
         return p_

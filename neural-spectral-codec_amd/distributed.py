@@ -178,11 +178,13 @@ class ShardedDescriptorPath:
 
     def __init__(self, encoder, gnn, n_total: int, poses=None, temporal_neighbors: int = 5,
                  n_layers: int = 3, group=None, overlap: bool = True, pipeline: bool = False,
-                 encoder_streams: int = 2, gnn_streams: int = 1):
+                 encoder_streams: int = 2, gnn_streams: int = 1, gnn_graph: bool = False):
         self.encoder, self.gnn, self.group = encoder, gnn, group
         self.pipeline = pipeline
         self.encoder_streams = max(1, int(encoder_streams))
         self.gnn_streams = max(1, int(gnn_streams))
+        self.gnn_graph = bool(gnn_graph)   # replay the GNN forward as a captured hipGraph (pipeline mode, eval)
+        self._gnn_graphs, self._gnn_warm = {}, {}
         self.coresident_gnn = True         # pipeline mode: launch the GNN in its NSC_GAT_CORESIDENT form
         self._k = 0
         self._streams = None
@@ -291,8 +293,8 @@ class ShardedDescriptorPath:
         # stream G and are read by the caller on ITS stream after synchronize(): tell the allocator, or the block
         # could be handed to a later step on stream G while those reads are still in flight
         for t in res:
-            if t.is_cuda:
-                t.record_stream(caller)
+            if t.is_cuda and not (self.gnn_graph and self._gnn_graphs.get(i) is not None):
+                t.record_stream(caller)      # (a captured forward's output lives in its graph's own pool)
         self.last_event = self._ev_gnn[i]
         self._k += 1
         return res
@@ -360,10 +362,40 @@ class ShardedDescriptorPath:
         else:
             desc_all = all_gather_descriptors(local, self.n_total, self.group)    # fresh tensor per step
             self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]
-        emb = self.gnn(self._graph)
+        emb = self._enhance()
         if work is not None:
             work.wait()
         return desc_all, emb[self._own0:self._own0 + n_local]
+
+    def _enhance(self):
+        """GNN forward over the window graph.  Pipeline mode on a HIP device: the forward's kernel launches are captured
+        once per rotating buffer into a hipGraph (torch.cuda.CUDAGraph: the C ABI only enqueues kernels on the stream it
+        is given, so a capturing stream records them) and replayed -- one graph launch per step instead of eight kernel
+        launches plus their Python plumbing (host issue 77 -> 19 us at 1 024 keyframes, device 77 -> 57 us alone; round
+        3).  A capture is keyed on the input's storage and the model's parameter versions: new weights or a new input
+        buffer recapture; an input that is not one of the rotating buffers (ragged shards) runs eagerly."""
+        x = self._graph.x
+        if not (self.gnn_graph and self.pipeline and x.is_cuda and not torch.is_grad_enabled()
+                and not getattr(self.gnn, "training", False)):
+            return self.gnn(self._graph)
+        slot = self._k % self._PIPE_BUFFERS
+        inner = getattr(self.gnn, "gnn", self.gnn)
+        key = (x.data_ptr(), tuple(x.shape),
+               tuple((t.data_ptr(), t._version) for t in list(inner.parameters()) + list(inner.buffers())),
+               bool(getattr(inner, "coresident", False)))
+        ent = self._gnn_graphs.get(slot)
+        if ent is not None and ent[0] == key:
+            ent[1].replay()
+            return ent[2]
+        if self._gnn_warm.get(slot) != key:              # first sight of this (buffer, weights): run it eagerly once
+            self._gnn_warm[slot] = key                   # (lazy set-up inside the forward must not be captured)
+            return self.gnn(self._graph)
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg, stream=torch.cuda.current_stream(x.device)):
+            out = self.gnn(self._graph)
+        cg.replay()                                      # the capture itself ran nothing
+        self._gnn_graphs[slot] = (key, cg, out)
+        return out
 
 
 def all_reduce_gradients(params, group=None, average: bool = False):

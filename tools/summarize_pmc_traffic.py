@@ -34,13 +34,13 @@ rd, wr = fa * 1024 * 2, wa * 1024
 tot, alg = rd + wr, alg_r + alg_w
 others = "; ".join(f"`{k}` FETCH {sum(v) / len(v):,.0f} / WRITE {sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1):,.0f}"
                    for k, v in fetch.items() if k != enc and ("gemm" in k or "aggregate" in k))
-md = f"""# Round 2 - HBM traffic of the encoder kernel (PMC counters)
+md = f"""# Round {tag[1:].lstrip("0")} - HBM traffic of the encoder kernel (PMC counters)
 
 Command (two separate passes, as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and WRITE_SIZE do
 not fit one pass; no trace domains besides --kernel-trace; tools/collect_profiles.sh {tag}, table by tools/summarize_pmc_traffic.py):
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/{tag}_profiles/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --pipelined
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/{tag}_profiles/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --pipelined
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/{tag}_profiles/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/{tag}_profiles/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras
 
 Per dispatch of `{enc}` (grid 1024 x 256 threads, 27.9 KB LDS, 1 024 clouds x 120 000 points), {len(f)} dispatches
 (counter mode serialises the two pipeline streams, so the figures are per kernel, undisturbed):

@@ -230,6 +230,9 @@ typedef struct NscGatTrainCfg {
     float    bn_momentum;          /* 0.1 (nn.BatchNorm1d default) */
     uint64_t seed;                 /* counter-based dropout masks: same seed in forward and backward */
     int32_t  update_running_stats; /* 1: running_mean / running_var of the model are updated IN PLACE */
+    const uint64_t *seed_dev;      /* nullable DEVICE pointer: when set, the kernels read the seed from this word at run
+                                      time instead of `seed` -- a training step captured into a hipGraph then replays
+                                      with a fresh mask per step (the caller rewrites the word between replays) */
 } NscGatTrainCfg;
 
 typedef struct NscGatGradLayer {   /* device buffers shaped like the NscGatLayer parameters; overwritten */

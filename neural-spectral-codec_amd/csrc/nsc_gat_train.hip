@@ -36,6 +36,14 @@ __host__ __device__ inline unsigned hash3(unsigned long long seed, unsigned stre
     z = z ^ (z >> 31);
     return (unsigned)(z >> 40);                        // 24 random bits
 }
+// The seed of a launch: a value baked into the kernel arguments, or -- when the caller gives NscGatTrainCfg.seed_dev -- a
+// device word read at run time, so that a captured hipGraph replays with a fresh mask per step.
+struct SeedRef {
+    unsigned long long v;
+    const unsigned long long *p;
+    __device__ __forceinline__ unsigned long long get() const { return p ? *p : v; }
+};
+
 __device__ __forceinline__ float keep_scale(float p, unsigned long long seed, unsigned stream,
                                             unsigned long long idx)
 {
@@ -155,16 +163,60 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 //   out_a[c] = sum_n P[n][c] * (w ? w[n] : 1)
 //   out_b[c] = sum_n P[n][c] * Q'[n][c],  Q' = Q or (Q - qm[c]) * qs[c]        (Q nullable)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__restrict__ P,
-                                                                const float *__restrict__ w,
-                                                                const float *__restrict__ Q,
-                                                                const float *__restrict__ qm,
-                                                                const float *__restrict__ qs, int N, int C,
-                                                                int rows_per_block, double *__restrict__ part)
+// mode 0: out_a = A, out_b = B (plain sums, nullable outputs)
+// mode 1: BatchNorm statistics of P (Q = P): mean = A/N, var = B/N - mean^2 -> out_a = mean,
+//         out_b = 1/sqrt(var+eps); optional running-stat update (momentum, unbiased variance)
+struct ColFinal {
+    int mode, N;
+    float eps, momentum;
+    float *out_a, *out_b, *run_mean, *run_var;
+};
+
+__device__ __forceinline__ void colreduce_finish(const double *__restrict__ part, int R, int C, int c, int cx, int ry,
+                                                 double *sa, double *sb, const ColFinal &f)
+{
+    // 64 columns per workgroup, the R partial rows split over the 4 waves (fixed order -> deterministic)
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = ry; r < R; r += 4) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    if (ry != 0 || c >= C) return;
+    a = (sa[cx] + sa[64 + cx]) + (sa[128 + cx] + sa[192 + cx]);
+    b = (sb[cx] + sb[64 + cx]) + (sb[128 + cx] + sb[192 + cx]);
+    if (f.mode == 0) {
+        if (f.out_a) f.out_a[c] = (float)a;
+        if (f.out_b) f.out_b[c] = (float)b;
+    } else {
+        const double mean = a / f.N;
+        double var = b / f.N - mean * mean;
+        if (var < 0.0) var = 0.0;
+        f.out_a[c] = (float)mean;
+        f.out_b[c] = (float)(1.0 / sqrt(var + (double)f.eps));
+        if (f.run_mean) {                                 // nn.BatchNorm1d: momentum 0.1, unbiased running_var
+            const double unb = f.N > 1 ? var * f.N / (f.N - 1) : var;
+            f.run_mean[c] = (1.0f - f.momentum) * f.run_mean[c] + f.momentum * (float)mean;
+            f.run_var[c] = (1.0f - f.momentum) * f.run_var[c] + f.momentum * (float)unb;
+        }
+    }
+}
+
+// The two passes in ONE launch (round 3: the 19 partial/final pairs of a training step were a fifth of its kernel
+// time and a quarter of its launches).  Every workgroup writes its float64 partials; the LAST one of a column block to
+// arrive -- a ticket from a device-scope atomic, partials released before it and acquired after it -- sums them in the
+// same fixed order as before: the result does not depend on which workgroup is last.  The ticket counter is reset by
+// that workgroup, so one zeroed counter array per C call serves every reduction of the call.
+__global__ __launch_bounds__(256) void colreduce_fused_kernel(const float *__restrict__ P, const float *__restrict__ w,
+                                                              const float *__restrict__ Q, const float *__restrict__ qm,
+                                                              const float *__restrict__ qs, int N, int C,
+                                                              int rows_per_block, double *__restrict__ part,
+                                                              unsigned *__restrict__ tickets, ColFinal f)
 {
     __shared__ double sa[256], sb[256];
+    __shared__ unsigned last;
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
+    const int R = gridDim.y;
     const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
     double a = 0.0, b = 0.0;
     if (c < C) {
@@ -187,43 +239,22 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__r
         part[((long long)blockIdx.y * C + c) * 2] = a;
         part[((long long)blockIdx.y * C + c) * 2 + 1] = b;
     }
-}
-
-// mode 0: out_a = A, out_b = B (plain sums, nullable outputs)
-// mode 1: BatchNorm statistics of P (Q = P): mean = A/N, var = B/N - mean^2 -> out_a = mean,
-//         out_b = 1/sqrt(var+eps); optional running-stat update (momentum, unbiased variance)
-__global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C,
-                                                              int mode, int N, float eps, float momentum,
-                                                              float *__restrict__ out_a, float *__restrict__ out_b,
-                                                              float *__restrict__ run_mean, float *__restrict__ run_var)
-{
-    // 64 columns per workgroup, the R partial rows split over the 4 waves (fixed order -> deterministic)
-    __shared__ double sa[256], sb[256];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = ry; r < R; r += 4) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
-    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
-    __syncthreads();
-    if (ry != 0 || c >= C) return;
-    a = (sa[cx] + sa[64 + cx]) + (sa[128 + cx] + sa[192 + cx]);
-    b = (sb[cx] + sb[64 + cx]) + (sb[128 + cx] + sb[192 + cx]);
-    if (mode == 0) {
-        if (out_a) out_a[c] = (float)a;
-        if (out_b) out_b[c] = (float)b;
-    } else {
-        const double mean = a / N;
-        double var = b / N - mean * mean;
-        if (var < 0.0) var = 0.0;
-        out_a[c] = (float)mean;
-        out_b[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (run_mean) {                                   // nn.BatchNorm1d: momentum 0.1, unbiased running_var
-            const double unb = N > 1 ? var * N / (N - 1) : var;
-            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
-            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
-        }
+    if (R == 1) {                                         // a single row block: it is the last one by construction
+        __syncthreads();
+        colreduce_finish(part, 1, C, c, cx, ry, sa, sb, f);
+        return;
     }
+    __threadfence();                                      // release: this workgroup's partials are visible device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (unsigned)R - 1u);
+        if (last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next reduction
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                      // acquire: the other workgroups' partials, not stale cache lines
+    colreduce_finish(part, R, C, c, cx, ry, sa, sb, f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ z
                                                      const float *__restrict__ invstd,
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int relu, float p,
-                                                     unsigned long long seed, unsigned stream,
+                                                     SeedRef seed, unsigned stream,
                                                      const float *__restrict__ resid, long long total, int C,
                                                      float *__restrict__ out)
 {
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ z
     const int c = (int)(i % C);
     float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
     if (relu) v = fmaxf(v, 0.0f);
-    v *= keep_scale(p, seed, stream, (unsigned long long)i);
+    v *= keep_scale(p, seed.get(), stream, (unsigned long long)i);
     if (resid) v += resid[i];
     out[i] = v;
 }
@@ -254,13 +285,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_dv_kernel(const float *__restr
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, int relu, float p,
-                                                            unsigned long long seed, unsigned stream,
+                                                            SeedRef seed, unsigned stream,
                                                             long long total, int C, float *__restrict__ dv)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % C);
-    float g = dh[i] * keep_scale(p, seed, stream, (unsigned long long)i);
+    float g = dh[i] * keep_scale(p, seed.get(), stream, (unsigned long long)i);
     if (relu) {
         const float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
         if (!(v > 0.0f)) g = 0.0f;
@@ -333,7 +364,7 @@ struct TrainAgg {
     float *alpha;                             // (nnz) softmax weights BEFORE dropout (saved)
     float *y;                                 // (N,H) aggregate + bias (pre-BatchNorm)
     float slope, p;
-    unsigned long long seed;
+    SeedRef seed;
     unsigned stream;
     int N, H, edge_dim;
 };
@@ -375,7 +406,7 @@ __global__ __launch_bounds__(256) void agg_train_kernel(TrainAgg a)
             float l = edge_raw(a, i, e, j); l = l > 0.f ? l : a.slope * l;
             al = expf(l - m) / s;
             a.alpha[e] = al;                                      // saved for the backward (pre-dropout)
-            ald = al * keep_scale(a.p, a.seed, a.stream, (unsigned long long)e);   // attention dropout
+            ald = al * keep_scale(a.p, a.seed.get(), a.stream, (unsigned long long)e);   // attention dropout
         }
         const int cnt = min(64, end - c0);
         for (int t = 0; t < cnt; ++t) {
@@ -404,7 +435,7 @@ struct AttBwdA {
     float *draw;        // (nnz) gradient of the pre-leaky-relu logit
     float *da_dst;      // (N)
     float slope, p;
-    unsigned long long seed;
+    SeedRef seed;
     unsigned stream;
     int N, H, edge_dim;
 };
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(256) void att_bwd_target_kernel(AttBwdA a)
         float d = 0.0f;
         for (int c = lane; c < a.H; c += 64)
             d = __builtin_fmaf(a.dY[(long long)i * a.H + c], a.G[(long long)j * a.H + c], d);
-        return wave_sumf(d) * keep_scale(a.p, a.seed, a.stream, (unsigned long long)e);
+        return wave_sumf(d) * keep_scale(a.p, a.seed.get(), a.stream, (unsigned long long)e);
     };
     float inner = 0.0f;                                       // sum_e alpha_e dalpha_e (wave-uniform)
     for (int e = beg; e < end; ++e) inner += a.alpha[e] * dalpha(e);
@@ -445,7 +476,7 @@ struct AttBwdB {
     float *dG;          // (N,H)
     float *da_src;      // (N)
     float p;
-    unsigned long long seed;
+    SeedRef seed;
     unsigned stream;
     int N, H;
 };
@@ -462,7 +493,7 @@ __global__ __launch_bounds__(256) void att_bwd_source_kernel(AttBwdB a)
         float acc = das * a.att_src[c] + dad * a.att_dst[c];
         for (int t = beg; t < end; ++t) {
             const int e = a.t_entry[t];
-            const float al = a.alpha[e] * keep_scale(a.p, a.seed, a.stream, (unsigned long long)e);
+            const float al = a.alpha[e] * keep_scale(a.p, a.seed.get(), a.stream, (unsigned long long)e);
             acc = __builtin_fmaf(al, a.dY[(long long)a.tgt[e] * a.H + c], acc);
         }
         a.dG[(long long)j * a.H + c] = acc;
@@ -653,12 +684,13 @@ __global__ __launch_bounds__(256) void triplet_reduce_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------
 constexpr int SPLITK_SLABS = 16;
 constexpr int COLRED_MAXR = 64;
+constexpr int COLRED_TICKETS = 64;        // column blocks of 64: up to 4 096 columns
 
 struct TrainWs {
     // saved by the forward
     size_t z0, mean0, invstd0, h, g, a_src, a_dst, alpha, y, mean, invstd, vvec;
     // backward scratch
-    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, total;
+    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, tickets, total;
     size_t nh, nn, hh, nz;
 };
 
@@ -695,6 +727,7 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
     w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);
     w.colpart = o; o += align256((size_t)COLRED_MAXR * std::max(std::max(H, m->out_dim), m->in_dim) * 2 * 8);
+    w.tickets = o; o += align256(COLRED_TICKETS * sizeof(unsigned));   // one per 64-column block, zero between reductions
     w.total = o;
     return w;
 }
@@ -718,16 +751,16 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
 }
 
 void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
-               int N, int C, double *part, int mode, float eps, float momentum, float *out_a, float *out_b,
-               float *run_mean, float *run_var)
+               int N, int C, double *part, unsigned *tickets, int mode, float eps, float momentum, float *out_a,
+               float *out_b, float *run_mean, float *run_var)
 {
     int R = (N + 63) / 64;
     if (R > COLRED_MAXR) R = COLRED_MAXR;
     if (R < 1) R = 1;
     const int rows = (N + R - 1) / R;
-    hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part);
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, mode, N, eps, momentum,
-                       out_a, out_b, run_mean, run_var);
+    const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var};
+    hipLaunchKernelGGL(colreduce_fused_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part,
+                       tickets, f);
 }
 
 inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
@@ -738,6 +771,7 @@ int check_train(const NscGatModel *m, const NscGraph *g)
     if (m->n_layers < 1 || m->n_layers > NSC_GAT_MAX_LAYERS) return NSC_EUNSUPPORTED;
     if (m->hidden < 16 || m->hidden > 1024 || (m->hidden & 15)) return NSC_EUNSUPPORTED;
     if (m->in_dim < 16 || (m->in_dim & 15) || m->out_dim < 4 || (m->out_dim & 3)) return NSC_EUNSUPPORTED;
+    if (m->in_dim > 64 * COLRED_TICKETS || m->out_dim > 64 * COLRED_TICKETS) return NSC_EUNSUPPORTED;   // column-reduction tickets
     if (m->edge_dim < 0 || m->edge_dim > NSC_GAT_MAX_EDGE_DIM) return NSC_EUNSUPPORTED;
     if (m->residual && m->in_dim != m->out_dim && (!m->res_w || !m->res_b)) return NSC_EINVAL;   // model.py:91-94
     if (!g->row_ptr || !g->src || !g->eid) return NSC_EINVAL;
@@ -789,17 +823,19 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
     char *b = static_cast<char *>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
+    unsigned *tickets = reinterpret_cast<unsigned *>(b + w.tickets);
+    if (hipMemsetAsync(tickets, 0, COLRED_TICKETS * sizeof(unsigned), st) != hipSuccess) return NSC_ELAUNCH;
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
     const int upd = cfg->update_running_stats;
 
     // input_proj (bias) -> z0 ; BatchNorm(batch stats) ; ReLU                 model.py:116-118
     gemm<false, false>(st, x, m->in_dim, m->in_w, m->in_dim, N, H, m->in_dim, F(w.z0), H, m->in_b, 0, 1, nullptr);
-    colreduce(st, F(w.z0), nullptr, F(w.z0), nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum,
+    colreduce(st, F(w.z0), nullptr, F(w.z0), nullptr, nullptr, N, H, colpart, tickets, 1, m->bn_eps, cfg->bn_momentum,
               F(w.mean0), F(w.invstd0), upd ? const_cast<float *>(m->in_bn_mean) : nullptr,
               upd ? const_cast<float *>(m->in_bn_var) : nullptr);
     hipLaunchKernelGGL(bn_act_kernel, dim3(blocks(NH)), dim3(256), 0, st, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
-                       m->in_bn_b, 1, 0.0f, 0ull, 0u, static_cast<const float *>(nullptr), NH, H, F(w.h));
+                       m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, static_cast<const float *>(nullptr), NH, H, F(w.h));
 
     for (int l = 0; l < L; ++l) {
         const NscGatLayer &Ly = m->layers[l];
@@ -817,15 +853,15 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
         a.edge_attr = use_edge ? edge_attr : nullptr;
         a.v = use_edge ? vv : nullptr;
         a.a_src = as; a.a_dst = ad; a.G = G; a.bias = Ly.bias; a.alpha = alpha; a.y = y;
-        a.slope = m->negative_slope; a.p = cfg->dropout_p; a.seed = cfg->seed; a.stream = 100u + l;
+        a.slope = m->negative_slope; a.p = cfg->dropout_p; a.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; a.stream = 100u + l;
         a.N = N; a.H = H; a.edge_dim = m->edge_dim;
         hipLaunchKernelGGL(agg_train_kernel, dim3((N + 3) / 4), dim3(256), 0, st, a);
-        colreduce(st, y, nullptr, y, nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum, mean, invstd,
+        colreduce(st, y, nullptr, y, nullptr, nullptr, N, H, colpart, tickets, 1, m->bn_eps, cfg->bn_momentum, mean, invstd,
                   upd ? const_cast<float *>(Ly.bn_mean) : nullptr, upd ? const_cast<float *>(Ly.bn_var) : nullptr);
         const int act = (l < L - 1);                                           // model.py:135-137
         const float *resid = (m->residual && l > 0 && l < L - 1) ? hin : nullptr;   // model.py:140-141
         hipLaunchKernelGGL(bn_act_kernel, dim3(blocks(NH)), dim3(256), 0, st, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
-                           act ? cfg->dropout_p : 0.0f, cfg->seed, 200u + l, resid, NH, H, hout);
+                           act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, resid, NH, H, hout);
     }
     // output_proj + input residual                                             model.py:144-151
     gemm<false, false>(st, F(w.h + w.nh * L), H, m->out_w, H, N, m->out_dim, H, out, m->out_dim, m->out_b, 0, 1, nullptr);
@@ -854,20 +890,22 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     char *b = static_cast<char *>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
+    unsigned *tickets = reinterpret_cast<unsigned *>(b + w.tickets);
+    if (hipMemsetAsync(tickets, 0, COLRED_TICKETS * sizeof(unsigned), st) != hipSuccess) return NSC_ELAUNCH;
     float *slabs = F(w.slabs);
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
     const int splits = N >= 512 ? SPLITK_SLABS : 1;
 
     // output_proj: out = h_L W_out^T + b (+ x)
-    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr);
+    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, tickets, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr);
     gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, 0, splits, slabs);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
     gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, nullptr);   // dh_L = dOut W_out
     const bool res_id = m->residual && Din == Dout, res_proj = m->residual && Din != Dout;
     if (res_proj) {                // residual_proj: dW_res = dOut^T x, db_res = colsum dOut      model.py:147-149
         if (!gr->res_w || !gr->res_b) return NSC_EINVAL;
-        colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr);
+        colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, tickets, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr);
         gemm<true, true>(st, grad_out, Dout, x, Din, Dout, Din, N, gr->res_w, Din, nullptr, 0, splits, slabs);
     }
     if (gr->x) {
@@ -894,14 +932,14 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         const bool has_res = (m->residual && l > 0 && l < L - 1);
         // h_{l+1} = drop(relu(bn(y))) [+ h_l]  ->  dV, BatchNorm backward -> dY (in place in dv)
         hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
-                           act ? cfg->dropout_p : 0.0f, cfg->seed, 200u + l, NH, H, dv);
-        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
+                           act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, NH, H, dv);
+        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, tickets, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
         if (hipMemcpyAsync(Gl.bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
         if (hipMemcpyAsync(Gl.bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, y, mean, invstd, Ly.bn_w, s1, s2, NH, H, N, dv);
         float *dY = dv;
         // conv bias
-        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr);
+        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr);
         // attention backward
         AttBwdA A;
         A.row_ptr = g->row_ptr; A.src = g->src; A.eid = g->eid;
@@ -909,18 +947,18 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         A.v = use_edge ? vv : nullptr;
         A.a_src = as; A.a_dst = ad; A.G = G; A.alpha = alpha; A.dY = dY;
         A.draw = F(w.draw); A.da_dst = F(w.da_dst);
-        A.slope = m->negative_slope; A.p = cfg->dropout_p; A.seed = cfg->seed; A.stream = 100u + l;
+        A.slope = m->negative_slope; A.p = cfg->dropout_p; A.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; A.stream = 100u + l;
         A.N = N; A.H = H; A.edge_dim = m->edge_dim;
         hipLaunchKernelGGL(att_bwd_target_kernel, dim3((N + 3) / 4), dim3(256), 0, st, A);
         AttBwdB Bk;
         Bk.t_ptr = g->t_ptr; Bk.t_entry = g->t_entry; Bk.tgt = g->tgt;
         Bk.alpha = alpha; Bk.dY = dY; Bk.draw = F(w.draw); Bk.da_dst = F(w.da_dst);
         Bk.att_src = Ly.att_src; Bk.att_dst = Ly.att_dst; Bk.dG = dG; Bk.da_src = F(w.da_src);
-        Bk.p = cfg->dropout_p; Bk.seed = cfg->seed; Bk.stream = 100u + l; Bk.N = N; Bk.H = H;
+        Bk.p = cfg->dropout_p; Bk.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; Bk.stream = 100u + l; Bk.N = N; Bk.H = H;
         hipLaunchKernelGGL(att_bwd_source_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Bk);
         // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
-        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr);
-        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr);
+        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr);
+        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr);
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
             if (use_edge) {
                 hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,
@@ -943,13 +981,13 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     // h_0 = relu(bn(z0)),  z0 = x W_in^T + b_in
     float *dv = F(w.dv), *s1 = F(w.s1), *s2 = F(w.s2);
     hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
-                       m->in_bn_b, 1, 0.0f, 0ull, 0u, NH, H, dv);
-    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
+                       m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, NH, H, dv);
+    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, tickets, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
     if (hipMemcpyAsync(gr->in_bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
     if (hipMemcpyAsync(gr->in_bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, s1, s2,
                        NH, H, N, dv);
-    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr);
+    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr);
     gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, 0, splits, slabs);
     if (gr->x) {   // + dZ0 W_in
         gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, nullptr);

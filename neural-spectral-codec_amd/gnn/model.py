@@ -105,12 +105,15 @@ class _GatTrainFunction(torch.autograd.Function):
     def forward(ctx, gnn, x, csr, dropout_p, seed, *params):
         L = _lib.lib()
         dev = x.device
-        m = gnn._model_struct()
+        m = gnn._train_struct()
         csr.ensure_transpose()
         g = csr.struct()
         cfg = _lib.GatTrainCfg()
         cfg.dropout_p, cfg.bn_momentum = float(dropout_p), float(gnn.input_norm.momentum or 0.1)
         cfg.seed, cfg.update_running_stats = int(seed), 1
+        sd = getattr(gnn, "_seed_dev", None)          # a device word the kernels read the seed from (captured steps)
+        cfg.seed_dev = sd.data_ptr() if sd is not None else None
+        ctx.seed_dev = sd
         n = int(x.shape[0])
         out = torch.empty((n, gnn.output_dim), dtype=torch.float32, device=dev)
         nbytes = L.nsc_gat_train_workspace_bytes(C.byref(m), C.byref(g))
@@ -131,7 +134,7 @@ class _GatTrainFunction(torch.autograd.Function):
         gnn, csr, x = ctx.gnn, ctx.csr, ctx.x
         L = _lib.lib()
         dev = x.device
-        m = gnn._model_struct()
+        m = gnn._train_struct()
         g = csr.struct()
         params = gnn._train_params()
         grads = [torch.empty_like(p) for p in params]
@@ -188,6 +191,7 @@ class SpectralGNN(nn.Module):
         # True: launch the LDS-free, low-VGPR kernel set (NSC_GAT_CORESIDENT) whose workgroups fit beside a
         # resident encoder grid -- used by distributed.ShardedDescriptorPath(pipeline=True).  Same output.
         self.coresident = False
+        self._seed_dev = None              # device int64[1]: dropout seed read by the kernels at run time (captured steps)
 
     # -- plumbing ---------------------------------------------------------------------------
     def __getstate__(self):
@@ -195,6 +199,8 @@ class SpectralGNN(nn.Module):
         state = self.__dict__.copy()
         state["_csr_cache"] = {}
         state["_struct_cache"] = None
+        state["_train_struct_cache"] = None
+        state["_seed_dev"] = None
         return state
 
     def _csr(self, data, use_edge_attr: bool) -> GraphCSR:
@@ -237,6 +243,18 @@ class SpectralGNN(nn.Module):
         _lib.check(st, "nsc_gat_fold_weights")
         self._struct_cache = (key, m, folded)
         return m
+
+    def _train_struct(self) -> _lib.GatModel:
+        """NscGatModel for nsc_gat_forward_train / nsc_gat_backward: pointers into the live parameter storage, no folded
+        attention vectors (the training kernels compute the attention dot products themselves, so an optimizer step
+        does not force a re-fold before the next forward).  Rebuilt only when a parameter's storage moves."""
+        params = list(self.parameters()) + list(self.buffers())
+        key = tuple(t.data_ptr() for t in params)
+        c = getattr(self, "_train_struct_cache", None)
+        if c is None or c[0] != key:
+            c = (key, self._build_struct())
+            self._train_struct_cache = c
+        return c[1]
 
     def _build_struct(self) -> _lib.GatModel:
         m = _lib.GatModel()
@@ -285,7 +303,9 @@ class SpectralGNN(nn.Module):
         _lib.require_cuda(x, "data.x")
         x = x.to(torch.float32).contiguous()
         csr = self._csr(data, use_edge_attr)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.dropout > 0 else 0
+        # seed of the counter-based dropout masks from torch's CPU generator; a captured step (GNNTrainer) keeps it in a
+        # device word instead (self._seed_dev), rewritten before every replay
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and getattr(self, "_seed_dev", None) is None) else 0
         return _GatTrainFunction.apply(self, x, csr, float(self.dropout), seed, *self._train_params())
 
     def _run(self, data, use_edge_attr: bool, want_alpha: bool):

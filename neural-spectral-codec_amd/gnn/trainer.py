@@ -91,7 +91,7 @@ class GNNTrainer:
     def __init__(self, model: nn.Module, device: str = 'cuda', learning_rate: float = 5e-4,
                  weight_decay: float = 1e-5, margin: float = 0.1, checkpoint_dir: Optional[str] = None,
                  log_interval: int = 10, use_multi_gpu: bool = True, patience: int = 10,
-                 batch_size: int = 1024, accumulation_steps: int = 4):
+                 batch_size: int = 1024, accumulation_steps: int = 4, use_graph: bool = True):
         self.model = model.to(device)
         self.device = device
         self.patience = patience                                                                      # :112
@@ -99,6 +99,9 @@ class GNNTrainer:
         self.optimizer = optim.Adam(model.parameters(), lr=learning_rate, weight_decay=weight_decay)  # :115-119
         self.criterion = TripletLoss(margin=margin)                                                   # :121
         self.batch_size, self.accumulation_steps = batch_size, accumulation_steps
+        # replay the per-batch step (forward + loss + backward) as a captured hipGraph from its second occurrence on
+        self.use_graph = use_graph
+        self._captured, self._seen_once, self._capture_failed = {}, set(), False
         # the reference creates 'checkpoints/' eagerly (:123-124); here the directory appears with the first save
         self.checkpoint_dir = Path(checkpoint_dir if checkpoint_dir is not None else 'checkpoints')
         self.log_interval = log_interval
@@ -247,32 +250,101 @@ class GNNTrainer:
         self.val_metrics = ck.get('val_metrics', [])
         self.epochs_without_improvement = ck.get('epochs_without_improvement', 0)
 
+    # -- the per-batch step, captured --------------------------------------------------------------------------
+    def _eager_step(self, graph, ia, ip, in_, scale):
+        embeddings = self.model(graph)                                                        # :205
+        loss = self.criterion.forward_indexed(embeddings, ia, ip, in_, scale=scale)           # :207-212
+        loss.backward()                                                                       # :213
+        return loss.detach()
+
+    def _captured_step(self, graph, bt, scale):
+        """forward + TripletLoss + backward of one batch as ONE hipGraph launch.  The step is ~75 small kernels
+        (1.2-1.8 ms per batch issued one by one, launch-bound; 0.73-1.04 ms replayed, round 3): everything it touches
+        is static -- the replicated graph, the parameter and gradient storage, the workspace of the capture's own
+        memory pool -- except three things fed through device buffers the capture reads: the triplet indices, and the
+        dropout seed (NscGatTrainCfg.seed_dev).  Gradients ACCUMULATE into the existing .grad tensors (the capture
+        holds their addresses: zero_grad must keep them, set_to_none=False).  Returns the loss, or None when capture is
+        not possible (then the caller runs the step eagerly)."""
+        if not self.use_graph or not torch.cuda.is_available() or torch.device(self.device).type != "cuda":
+            return None
+        inner = getattr(self.model, "gnn", self.model)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        T = int(len(bt))
+        key = (id(graph), graph.x.data_ptr(), graph.edge_index.data_ptr(), T, float(scale),
+               tuple(p.data_ptr() for p in params))
+        ent = self._captured.get(key)
+        dev = graph.x.device
+        if ent is None:
+            if self._capture_failed:
+                return None
+            if key not in self._seen_once:
+                self._seen_once.add(key)                    # first batch of this shape runs eagerly (lazy set-up, warm-up)
+                return None
+            try:
+                idx = [torch.empty(T, dtype=torch.int64, device=dev) for _ in range(3)]
+                seed = torch.zeros(1, dtype=torch.int64, device=dev)
+                for p in params:                            # static gradient storage
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                inner._seed_dev = seed
+                torch.cuda.synchronize(dev)
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):                  # records the launches; nothing runs until replay()
+                    loss = self._eager_step(graph, idx[0], idx[1], idx[2], scale)
+                ent = (cg, idx, seed, loss, [p.grad for p in params])
+                self._captured[key] = ent
+            except Exception as ex:  # noqa: BLE001 -- any capture problem: fall back to issuing the step eagerly
+                logging.warning(f"hipGraph capture of the training step failed ({type(ex).__name__}: {ex}); running eagerly")
+                self._capture_failed = True
+                return None
+            finally:
+                inner._seed_dev = None
+        cg, idx, seed, loss, grads = ent
+        for p, g in zip(params, grads):
+            if p.grad is not g:                             # someone dropped / replaced the static gradient tensor
+                if p.grad is not None:
+                    g.copy_(p.grad)
+                else:
+                    g.zero_()
+                p.grad = g
+        h = np.ascontiguousarray(np.asarray(bt), dtype=np.int64)
+        n = int(graph.x.shape[0])
+        if h.size and (h.min() < -n or h.max() >= n):
+            raise IndexError(f"triplet index out of range for {n} embeddings")
+        for j in range(3):
+            idx[j].copy_(torch.from_numpy(np.ascontiguousarray(h[:, j])))
+        seed.fill_(int(torch.randint(0, 2 ** 62, (1,)).item()) if float(getattr(inner, "dropout", 0.0)) > 0 else 0)
+        cg.replay()                                         # (num_batches_tracked is incremented inside the capture)
+        return loss.detach().clone()
+
     def train_batches(self, graph, triplets: Sequence) -> float:
         """trainer.py:186-231 for an (n,3) array of (anchor, positive, negative) triplets."""
         self.model.train()
         triplets = np.asarray(triplets)
         n_batches = (len(triplets) + self.batch_size - 1) // self.batch_size
         losses = []
-        self.optimizer.zero_grad()
         from .. import distributed as nd
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        # gradients keep their storage across optimizer steps (a captured step holds their addresses)
+        self.optimizer.zero_grad(set_to_none=False)
         for b in range(n_batches):
             bt = triplets[b * self.batch_size:(b + 1) * self.batch_size]
             # data parallel over ranks: the graph forward is replicated, each rank takes a slice of the
             # triplet batch; weighting by slice size makes the summed gradients those of the global mean
             bt, weight = nd.split_triplets(bt, rank, world) if world > 1 else (bt, 1.0)
-            embeddings = self.model(graph)                                                    # :205
-            loss = self.criterion.forward_indexed(embeddings, bt[:, 0], bt[:, 1], bt[:, 2],
-                                                  scale=weight / self.accumulation_steps)     # :207-212
-            loss.backward()                                                                   # :213
-            losses.append(loss.detach())
+            scale = weight / self.accumulation_steps
+            loss = self._captured_step(graph, bt, scale) if len(bt) else None
+            if loss is None:
+                loss = self._eager_step(graph, bt[:, 0], bt[:, 1], bt[:, 2], scale)
+            losses.append(loss)
             self.global_step += 1
             if (b + 1) % self.accumulation_steps == 0 or (b + 1) == n_batches:                # :219-221
-                nd.all_reduce_gradients(list(self.model.parameters()))     # one 2.46 MB RCCL all-reduce
+                nd.all_reduce_gradients(params)                            # one 2.46 MB RCCL all-reduce
                 self.optimizer.step()
-                self.optimizer.zero_grad()
+                self.optimizer.zero_grad(set_to_none=False)
         if not losses:
             return 0.0
         return float(torch.stack(losses).mean().item() * self.accumulation_steps)

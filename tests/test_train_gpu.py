@@ -432,3 +432,48 @@ def test_trainer_epoch_loop_and_checkpoints(tmp_path):
         assert torch.equal(m(graph), m2(graph))
     with pytest.raises(FileNotFoundError):
         tr2.load_checkpoint("missing.pth")
+
+
+def test_captured_training_step_matches_eager():
+    """GNNTrainer replays the per-batch step (forward_train + TripletLoss + backward, ~75 launches) as ONE captured
+    hipGraph from the second batch of a shape on.  Dropout 0: the parameters after 2 optimizer steps (8 batches, one
+    ragged) must equal the eagerly issued run's up to the float32 atomics of the triplet scatter.  Dropout 0.1: the
+    seed lives in a device word the kernels read (NscGatTrainCfg.seed_dev) -- two replays of the SAME batch draw
+    different masks, and training still reduces the loss."""
+    n = 600
+    rng = np.random.default_rng(2)
+    trip = np.stack([rng.integers(0, n, 1800), rng.integers(0, n, 1800), rng.integers(0, n, 1800)], 1)   # 7 x 256 + 8
+    outs = []
+    for use_graph in (False, True):
+        m, g, _ = _setup(n, 2)
+        tr = GNNTrainer(m, device="cuda", learning_rate=5e-4, weight_decay=1e-5, margin=0.1, batch_size=256,
+                        accumulation_steps=4, use_graph=use_graph)
+        loss = tr.train_batches(g, trip)
+        assert bool(tr._captured) == use_graph and not tr._capture_failed
+        outs.append((loss, {k: v.detach().cpu().clone() for k, v in m.gnn.named_parameters()},
+                     m.gnn.input_norm.running_mean.cpu().clone(), int(m.gnn.input_norm.num_batches_tracked)))
+    (l0, p0, rm0, nb0), (l1, p1, rm1, nb1) = outs
+    assert nb0 == nb1 == 8
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) + 1e-7
+    assert torch.allclose(rm0, rm1, rtol=1e-5, atol=1e-7)
+    for k in p0:
+        # two Adam steps; elements whose gradient is rounding noise may step by +-lr on either side
+        assert (p0[k] - p1[k]).abs().max().item() <= 2.5 * 5e-4, k
+        frac = ((p0[k] - p1[k]).abs() > 1e-6).float().mean().item()
+        assert frac < 0.02, (k, frac)
+    # dropout > 0 through the capture: fresh masks per replay
+    m, g, _ = _setup(n, 2, dropout=0.1)
+    tr = GNNTrainer(m, device="cuda", batch_size=256, accumulation_steps=1, use_graph=True)
+    m.train()
+    bt = trip[:256]
+    torch.manual_seed(11)
+    assert tr._captured_step(g, bt, 1.0) is None                 # first sight of the shape: the caller runs it eagerly
+    l_a = float(tr._captured_step(g, bt, 1.0))                   # capture + replay
+    l_b = float(tr._captured_step(g, bt, 1.0))                   # replay: same batch, same weights, a new seed in the device word
+    l_c = float(tr._captured_step(g, bt, 1.0))
+    assert tr._captured and not tr._capture_failed
+    assert len({round(v, 7) for v in (l_a, l_b, l_c)}) == 3, (l_a, l_b, l_c)   # three masks -> three losses
+    m2, g2, trip2 = _setup(400, 2, dropout=0.1)
+    tr2 = GNNTrainer(m2, device="cuda", learning_rate=5e-4, batch_size=256, accumulation_steps=1)
+    ls = [tr2.train_batches(g2, np.concatenate([trip2] * 2)) for _ in range(8)]
+    assert tr2._captured and ls[-1] < ls[0]

@@ -455,7 +455,9 @@ def test_captured_training_step_matches_eager():
     (l0, p0, rm0, nb0), (l1, p1, rm1, nb1) = outs
     assert nb0 == nb1 == 8
     assert abs(l0 - l1) <= 1e-5 * abs(l0) + 1e-7
-    assert torch.allclose(rm0, rm1, rtol=1e-5, atol=1e-7)
+    # (after the first optimizer step the two runs' weights differ by +-lr where a gradient is rounding noise, see below;
+    #  rows of x sum to 1, so the input projection's batch mean may move by a few lr)
+    assert torch.allclose(rm0, rm1, rtol=0, atol=4 * 5e-4)
     for k in p0:
         # two Adam steps; elements whose gradient is rounding noise may step by +-lr on either side
         assert (p0[k] - p1[k]).abs().max().item() <= 2.5 * 5e-4, k

@@ -458,9 +458,13 @@ def test_captured_training_step_matches_eager():
     # (after the first optimizer step the two runs' weights differ by +-lr where a gradient is rounding noise, see below;
     #  rows of x sum to 1, so the input projection's batch mean may move by a few lr)
     assert torch.allclose(rm0, rm1, rtol=0, atol=4 * 5e-4)
+    zero = {"input_proj.bias"} | {f"convs.{l}.bias" for l in range(3)}     # exactly-zero gradients: pure rounding noise
     for k in p0:
-        # two Adam steps; elements whose gradient is rounding noise may step by +-lr on either side
-        assert (p0[k] - p1[k]).abs().max().item() <= 2.5 * 5e-4, k
+        # two Adam steps: an element whose gradient is rounding noise steps by +-lr per step on either side (4 lr apart at
+        # most); everywhere else the two runs take the same steps
+        assert (p0[k] - p1[k]).abs().max().item() <= 4.2 * 5e-4, k
+        if k in zero:
+            continue
         frac = ((p0[k] - p1[k]).abs() > 1e-6).float().mean().item()
         assert frac < 0.02, (k, frac)
     # dropout > 0 through the capture: fresh masks per replay

@@ -257,7 +257,7 @@ class GNNTrainer:
         loss.backward()                                                                       # :213
         return loss.detach()
 
-    def _captured_step(self, graph, bt, scale):
+    def _captured_step(self, graph, bt, scale, bt_dev=None):
         """forward + TripletLoss + backward of one batch as ONE hipGraph launch.  The step is ~75 small kernels
         (1.2-1.8 ms per batch issued one by one, launch-bound; 0.73-1.04 ms replayed, round 3): everything it touches
         is static -- the replicated graph, the parameter and gradient storage, the workspace of the capture's own
@@ -312,7 +312,10 @@ class GNNTrainer:
         if h.size and (h.min() < -n or h.max() >= n):
             raise IndexError(f"triplet index out of range for {n} embeddings")
         for j in range(3):
-            idx[j].copy_(torch.from_numpy(np.ascontiguousarray(h[:, j])))
+            # bt_dev: the batch's (3, T) index rows already on the device (train_batches uploads an epoch's triplets once:
+            # a per-batch copy from pageable host memory would block the host until the stream has drained)
+            idx[j].copy_(bt_dev[j] if bt_dev is not None else torch.from_numpy(np.ascontiguousarray(h[:, j])),
+                         non_blocking=True)
         seed.fill_(int(torch.randint(0, 2 ** 62, (1,)).item()) if float(getattr(inner, "dropout", 0.0)) > 0 else 0)
         cg.replay()                                         # (num_batches_tracked is incremented inside the capture)
         return loss.detach().clone()
@@ -330,13 +333,22 @@ class GNNTrainer:
         params = [p for p in self.model.parameters() if p.requires_grad]
         # gradients keep their storage across optimizer steps (a captured step holds their addresses)
         self.optimizer.zero_grad(set_to_none=False)
+        trip_dev = None
+        if self.use_graph and len(triplets) and torch.device(self.device).type == "cuda" and torch.cuda.is_available():
+            trip_dev = torch.from_numpy(np.ascontiguousarray(triplets.T, dtype=np.int64)).to(graph.x.device)   # (3, n), once
         for b in range(n_batches):
-            bt = triplets[b * self.batch_size:(b + 1) * self.batch_size]
+            b0 = b * self.batch_size
+            bt = triplets[b0:b0 + self.batch_size]
+            lo, hi = 0, len(bt)
             # data parallel over ranks: the graph forward is replicated, each rank takes a slice of the
             # triplet batch; weighting by slice size makes the summed gradients those of the global mean
-            bt, weight = nd.split_triplets(bt, rank, world) if world > 1 else (bt, 1.0)
+            weight = 1.0
+            if world > 1:
+                lo, hi = nd.shard_range(len(bt), rank, world)
+                bt, weight = nd.split_triplets(bt, rank, world)
             scale = weight / self.accumulation_steps
-            loss = self._captured_step(graph, bt, scale) if len(bt) else None
+            bt_dev = trip_dev[:, b0 + lo:b0 + hi] if trip_dev is not None else None
+            loss = self._captured_step(graph, bt, scale, bt_dev) if len(bt) else None
             if loss is None:
                 loss = self._eager_step(graph, bt[:, 0], bt[:, 1], bt[:, 2], scale)
             losses.append(loss)

@@ -381,7 +381,8 @@ class ShardedDescriptorPath:
         slot = self._k % self._PIPE_BUFFERS
         inner = getattr(self.gnn, "gnn", self.gnn)
         key = (x.data_ptr(), tuple(x.shape),
-               tuple((t.data_ptr(), t._version) for t in list(inner.parameters()) + list(inner.buffers())),
+               tuple((t.data_ptr(), t._version) for t in (inner._live_tensors() if hasattr(inner, "_live_tensors")
+                                                          else list(inner.parameters()) + list(inner.buffers()))),
                bool(getattr(inner, "coresident", False)))
         ent = self._gnn_graphs.get(slot)
         if ent is not None and ent[0] == key:

@@ -440,7 +440,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "encoder_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") if n_local == N_CLOUDS else None
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {

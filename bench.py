@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--calibrate", action="store_true", help=argparse.SUPPRESS)      # time all three step implementations
     ap.add_argument("--gnn-streams", type=int, default=1, help=argparse.SUPPRESS)    # GNN passes alternate over this many streams
     ap.add_argument("--gnn-graph", type=int, default=0, help=argparse.SUPPRESS)      # 1: replay the GNN forward as a hipGraph
+    ap.add_argument("--no-gnn", action="store_true", help=argparse.SUPPRESS)         # DIAGNOSTIC (not the metric): identity in place of the GNN
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -291,8 +292,13 @@ def main():
         def encode_points_batch(clouds):
             return enc.encode_points_batch(clouds, out=desc_local)
 
+    class _NoGnn:                                           # --no-gnn: what the step machinery costs without the GNN's kernels
+        def __call__(self, g):
+            return g.x
+
     def make_path(pipelined, enc_streams=1):
-        p_ = nd.ShardedDescriptorPath(enc, model, n_total, poses, pipeline=pipelined, encoder_streams=enc_streams,
+        p_ = nd.ShardedDescriptorPath(enc, _NoGnn() if args.no_gnn else model, n_total, poses, pipeline=pipelined,
+                                      encoder_streams=enc_streams,
                                       gnn_streams=args.gnn_streams, gnn_graph=bool(args.gnn_graph))
         if not pipelined:
             p_.encoder = _Enc
@@ -444,7 +450,7 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
-            "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds",
+            "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds" + (" -- DIAGNOSTIC RUN WITHOUT THE GNN, not the metric" if args.no_gnn else ""),
             "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,

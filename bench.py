@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--enc-streams", type=int, default=0, choices=[0, 1, 2], help=argparse.SUPPRESS)
     ap.add_argument("--one-batch", action="store_true", help=argparse.SUPPRESS)      # every step reads the same batch
     ap.add_argument("--calibrate", action="store_true", help=argparse.SUPPRESS)      # time all three step implementations
+    ap.add_argument("--calibrate2", action="store_true", help=argparse.SUPPRESS)     # the N > 1 choice (pipelined2 / serial) at N = 1
     ap.add_argument("--gnn-streams", type=int, default=1, help=argparse.SUPPRESS)    # GNN passes alternate over this many streams
     ap.add_argument("--gnn-graph", type=int, default=0, help=argparse.SUPPRESS)      # 1: replay the GNN forward as a hipGraph
     ap.add_argument("--no-gnn", action="store_true", help=argparse.SUPPRESS)         # DIAGNOSTIC (not the metric): identity in place of the GNN
@@ -320,7 +321,7 @@ def main():
         want = ["pipelined1" if args.enc_streams == 1 else "pipelined2"]
     elif args.calibrate:
         want = ["pipelined2", "pipelined1", "serial"]
-    elif world == 1:
+    elif world == 1 and not args.calibrate2:
         want = ["pipelined1" if args.enc_streams == 1 else "pipelined2"]
     else:
         want = ["pipelined1" if args.enc_streams == 1 else "pipelined2", "serial"]

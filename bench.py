@@ -311,8 +311,8 @@ def main():
     # One GPU: pipelined2, no calibration -- it won every interleaved comparison of round 3 (3.19-3.38 M keyframes/s
     # against 3.02 / 2.78 M), and a process that sets up several step implementations side by side runs its FIRST timed
     # region on a fresh box 8-10 % slower (7 of 7 fresh boxes; cause not found).  N > 1: the
-    # pipelined path meets RCCL kernels it could not be measured against, so a short untimed calibration picks between
-    # pipelined2 and serial (all ranks agree through an all-reduce).  --calibrate: all three, any N.
+    # pipelined paths meet RCCL kernels they could not be measured against, so a short untimed calibration picks among
+    # the three (all ranks agree through an all-reduce).  --calibrate: all three at N = 1 too.
     paths = {}
     want = []
     if args.serial:
@@ -323,8 +323,12 @@ def main():
         want = ["pipelined2", "pipelined1", "serial"]
     elif world == 1 and not args.calibrate2:
         want = ["pipelined1" if args.enc_streams == 1 else "pipelined2"]
+    elif args.calibrate2:
+        want = ["pipelined2", "serial"]
     else:
-        want = ["pipelined1" if args.enc_streams == 1 else "pipelined2", "serial"]
+        # N > 1: RCCL's all-gather kernel has to find room beside the resident encoder grid -- with overlapping launches
+        # there is no gap between two encoder launches any more, with one encoder stream there is: let the box decide
+        want = (["pipelined2"] if args.enc_streams != 1 else []) + ["pipelined1", "serial"]
     for name_ in want:
         paths[name_] = make_path(name_ != "serial", 2 if name_ == "pipelined2" else 1)
     for name_, p_ in paths.items():

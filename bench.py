@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--calibrate2", action="store_true", help=argparse.SUPPRESS)     # the N > 1 choice (pipelined2 / serial) at N = 1
     ap.add_argument("--gnn-streams", type=int, default=1, help=argparse.SUPPRESS)    # GNN passes alternate over this many streams
     ap.add_argument("--gnn-graph", type=int, default=0, help=argparse.SUPPRESS)      # 1: replay the GNN forward as a hipGraph
+    ap.add_argument("--gnn-nodes", type=int, default=0, help=argparse.SUPPRESS)      # DIAGNOSTIC: GNN over the first n keyframes only
     ap.add_argument("--no-gnn", action="store_true", help=argparse.SUPPRESS)         # DIAGNOSTIC (not the metric): identity in place of the GNN
     args = ap.parse_args()
 
@@ -297,8 +298,20 @@ def main():
         def __call__(self, g):
             return g.x
 
+    class _PartGnn:                                         # --gnn-nodes n: is the GNN's cost beside the encoder work- or launch-bound?
+        def __init__(self, n):
+            from neural_spectral_codec_amd.keyframe import graph_manager as gm_
+            self.n, self.g = n, gm_.synthetic_chain_graph(n, device=dev, seed=1)
+
+        def __call__(self, g):
+            self.g.x = g.x[:self.n]
+            out = torch.empty_like(g.x)
+            out[:self.n] = model(self.g)
+            return out
+
     def make_path(pipelined, enc_streams=1):
-        p_ = nd.ShardedDescriptorPath(enc, _NoGnn() if args.no_gnn else model, n_total, poses, pipeline=pipelined,
+        gnn_ = _NoGnn() if args.no_gnn else (_PartGnn(args.gnn_nodes) if args.gnn_nodes else model)
+        p_ = nd.ShardedDescriptorPath(enc, gnn_, n_total, poses, pipeline=pipelined,
                                       encoder_streams=enc_streams,
                                       gnn_streams=args.gnn_streams, gnn_graph=bool(args.gnn_graph))
         if not pipelined:
@@ -455,7 +468,7 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
-            "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds" + (" -- DIAGNOSTIC RUN WITHOUT THE GNN, not the metric" if args.no_gnn else ""),
+            "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds" + (" -- DIAGNOSTIC RUN WITHOUT THE FULL GNN, not the metric" if (args.no_gnn or args.gnn_nodes) else ""),
             "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,

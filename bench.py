@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)   # skip the untimed side measurements
-    ap.add_argument("--gnn-kernels", choices=["auto", "lds", "direct"], default="auto", help=argparse.SUPPRESS)
+    ap.add_argument("--gnn-kernels", choices=["auto", "lds", "direct", "shared_b"], default="auto", help=argparse.SUPPRESS)
     ap.add_argument("--ev-every", type=int, default=EV_EVERY, help=argparse.SUPPRESS)   # time every n-th encoder launch
     ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)      # force the one-stream path
     ap.add_argument("--pipelined", action="store_true", help=argparse.SUPPRESS)   # force the software-pipelined path
@@ -345,7 +345,7 @@ def main():
     for name_ in want:
         paths[name_] = make_path(name_ != "serial", 2 if name_ == "pipelined2" else 1)
     for name_, p_ in paths.items():
-        p_.coresident_gnn = name_ != "serial" and args.gnn_kernels != "lds"
+        p_.coresident_gnn = (name_ != "serial" and args.gnn_kernels != "lds") and ("shared_b" if args.gnn_kernels == "shared_b" else True)
     path = next(iter(paths.values()))
 
     def sync():
@@ -359,7 +359,8 @@ def main():
         nonlocal path
         path = paths[name]
         # LDS-free GNN kernels only where they co-run with a resident encoder grid
-        inner_gnn.coresident = (name != "serial") if args.gnn_kernels == "auto" else (args.gnn_kernels == "direct")
+        inner_gnn.coresident = ((name != "serial") if args.gnn_kernels == "auto" else
+                                {"direct": True, "lds": False, "shared_b": "shared_b"}[args.gnn_kernels])
 
     SPINUP_STEPS = 40    # untimed device spin-up (clock ramp, TLB/first touch): ~16 ms, part of setup
     calib = None

@@ -212,10 +212,14 @@ size_t nsc_gat_workspace_bytes(const NscGatModel *m, int32_t n_nodes);
  *   alpha_out  nullable (n_layers, nnz) attention coefficients (forward_with_attention) */
 int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                     float *out, float *alpha_out, void *ws, size_t ws_bytes, void *stream);
-/* Same forward with launch options.  NSC_GAT_CORESIDENT: every kernel uses 0 bytes of LDS and < 96 VGPRs, so its
- * workgroups fit on the CUs beside a fully resident nsc_encode_clouds grid (4 workgroups/CU leave 2.3 KB of LDS):
- * issue it on a second stream to run the GNN of batch k under the encoder of batch k+1.  Bit-identical output. */
+/* Same forward with launch options.  NSC_GAT_CORESIDENT: every kernel uses 0 bytes of LDS and <= 56 VGPRs, so two waves
+ * of it fit on a SIMD beside a resident nsc_encode_clouds grid (up to five encoder workgroups per CU: 5 x 27.9 KB of LDS,
+ * 5 x 80 VGPRs): issue it on its own stream to run the GNN of batch k under the encoders of batches k+1, k+2.
+ * NSC_GAT_SHARED_B (with NSC_GAT_CORESIDENT): the GEMMs use 64 x 64 tiles that share the weight block through 10 KB of LDS
+ * (two such workgroups fit in the 20 KB a CU has left beside five encoder workgroups): fewer LDS-pipe and L1 operations
+ * per FLOP.  Bit-identical output in every combination. */
 #define NSC_GAT_CORESIDENT 1u
+#define NSC_GAT_SHARED_B 2u
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream);
 

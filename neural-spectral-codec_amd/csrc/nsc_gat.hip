@@ -527,6 +527,125 @@ __global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small-LDS co-resident GEMM (NSC_GAT_CORESIDENT | NSC_GAT_SHARED_B, round 3).  Beside the encoder the GNN costs its
+// THROUGHPUT share, not its latency (experiment 17c), and gemm_nt_direct_kernel spends per MFMA two
+// ds_bpermute (on the LDS pipe the encoder's ds_min atomics use), half a 16-byte load and the addressing around them:
+// its 16 x 64 workgroup tile re-reads the whole B (weight) tile for 16 rows, and its four waves each fetch and transpose
+// the same A rows.  Here a workgroup owns 64 rows x 64 columns: every wave its own 16 rows (A: one coalesced load + 4
+// bpermutes per 16-k block, as before) and all 64 columns (4 accumulators); the B block (64 columns x 16 k = 4 KB) is
+// loaded ONCE per workgroup -- one 16-byte load per thread -- and shared through a double-buffered 2 x 5 KB LDS tile that
+// the waves read as MFMA operands (ds_read_b128).  Per 16 MFMAs: 2 loads, 4 bpermutes, 1 ds_write, 4 ds_read (the direct
+// kernel: 8 loads, 32 bpermutes), and B is fetched from L2 a quarter as often.  10 KB of LDS: two workgroups fit in the 20 KB
+// a CU has left beside five resident encoder workgroups.  Same k order and operand assignment as the other GEMMs: the
+// results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_share_kernel(const float *__restrict__ A, int lda,
+                                                            const float *__restrict__ B, int ldb,
+                                                            const float *__restrict__ Bx, int M, int N,
+                                                            int n_main, int K, float *__restrict__ C, int ldc,
+                                                            GemmEpi ep)
+{
+    constexpr int LDB = 20;                        // floats per staged B column: 16 k + 4 of padding (bank spread)
+    __shared__ __attribute__((aligned(16))) float Bs[2][64 * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int m0 = (int)(tile / gridDim.x) * 64 + 16 * wave, n0 = (int)(tile % gridDim.x) * 64;
+
+    // A: this wave's 16 rows, coalesced map (lane L: row L >> 2, k offset 4 (L & 3)) + ds_bpermute to the operand layout
+    const int lr = lane >> 2, lq = lane & 3;
+    const int perm = 4 * (4 * r + q);
+    const int gr = m0 + lr;
+    const float *pa = A + (long long)(gr < M ? gr : M - 1) * lda + 4 * lq;
+    // B: thread t stages column t >> 2 at k offset 4 (t & 3) -- 4 lanes read 64 contiguous bytes
+    const int sc = tid >> 2, sq = tid & 3;
+    int gc = n0 + sc;
+    gc = gc < N ? gc : N - 1;
+    const float *pb = ((gc < n_main) ? B + (long long)gc * ldb : Bx + (long long)(gc - n_main) * ldb) + 4 * sq;
+    const int sidx = sc * LDB + 4 * sq;
+    auto to_operand = [&](const f32x4 &v) {
+        f32x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float e = v[t];
+            o[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm, __float_as_int(e)));
+        }
+        return o;
+    };
+    const int ncb = min(4, (N - n0 + 15) >> 4);    // 16-column blocks of this tile that hold real columns (uniform)
+
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {zero, zero, zero, zero};
+    const int nblk = K >> 4;                       // K is a multiple of 16 (check_model)
+    f32x4 ra[2], rb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int k = (s < nblk ? s : nblk - 1) << 4;
+        ra[s] = *reinterpret_cast<const f32x4 *>(pa + k);
+        rb[s] = *reinterpret_cast<const f32x4 *>(pb + k);
+    }
+    *reinterpret_cast<f32x4 *>(&Bs[0][sidx]) = rb[0];
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int blk = b0 + s;
+            if (blk < nblk) {                      // workgroup-uniform
+                const float *bs = Bs[s];
+                // B of block blk + 1 goes to the other buffer (last read in iteration blk - 1, a barrier ago)
+                if (blk + 1 < nblk) *reinterpret_cast<f32x4 *>(&Bs[s ^ 1][sidx]) = rb[s ^ 1];
+                const f32x4 xa = to_operand(ra[s]);
+                if (blk + 2 < nblk) {              // both register sets of this parity are free: refill two blocks ahead
+                    const int k = (blk + 2) << 4;
+                    ra[s] = *reinterpret_cast<const f32x4 *>(pa + k);
+                    rb[s] = *reinterpret_cast<const f32x4 *>(pb + k);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g < ncb) {
+                        const f32x4 xb = *reinterpret_cast<const f32x4 *>(&bs[(16 * g + r) * LDB + 4 * q]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t], xb[t], acc[g], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cb = n0 + 16 * g + r;
+        if (cb >= N) continue;
+        const bool main_col = cb < n_main;
+        float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
+        if (EPI != 0 && main_col) bias = ep.bias[cb];
+        if (EPI == 1 && main_col) {
+            const float invstd = 1.0f / sqrtf(ep.bn_var[cb] + ep.bn_eps);
+            bn_scale = invstd * ep.bn_w[cb];
+            bn_shift = ep.bn_b[cb] - ep.bn_mean[cb] * bn_scale;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = m0 + 4 * q + reg;
+            if (row >= M) continue;
+            float v = acc[g][reg];
+            if (main_col) {
+                if (EPI != 0) v = v + bias;
+                if (EPI == 1) v = fmaxf(v * bn_scale + bn_shift, 0.0f);
+                if (EPI == 2 && ep.resid) v = v + ep.resid[(long long)row * ep.ldr + cb];
+                C[(long long)row * ldc + cb] = v;
+            } else {
+                float *aux = (cb == n_main) ? ep.aux0 : ep.aux1;
+                aux[row] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention + aggregation, one wavefront per target node
 // ---------------------------------------------------------------------------------------------
 struct AggArgs {
@@ -760,12 +879,18 @@ int gat_tune_env(const char *name, int def)
 #endif
 
 template <int EPI>
-void launch_gemm(hipStream_t st, bool coresident, const float *A, int lda, const float *B, int ldb, const float *Bx,
+void launch_gemm(hipStream_t st, int cores, const float *A, int lda, const float *B, int ldb, const float *Bx,
                  int M, int N, int n_main, int K, float *C, int ldc, const GemmEpi &ep)
 {
     // Tile choice (measured at M = 1 024 and 4 541, round 2): 32-row tiles (two accumulators share the B operand, 1.7x
     // less operand traffic per MFMA) as soon as they still give >= 1.5 workgroups per CU; below that 16-row tiles, so
     // that every SIMD of the chip gets a wave -- these GEMMs are operand-latency-, not MFMA-bound.
+    const bool coresident = cores != 0;
+    if (cores == 2) {                              // small-LDS co-resident form: 64 x 64 tiles, B shared through 10 KB of LDS
+        const dim3 gs((N + 63) / 64, (M + 63) / 64);
+        hipLaunchKernelGGL((gemm_nt_share_kernel<EPI>), gs, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep);
+        return;
+    }
     const long long w2 = (long long)((N + 63) / 64) * ((M + 31) / 32);
     const long long w4 = (long long)((N + 63) / 64) * ((M + 63) / 64);
     bool two = w2 >= 384 && !coresident;
@@ -907,8 +1032,9 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream_)
 {
-    if (flags & ~(uint32_t)NSC_GAT_CORESIDENT) return NSC_EINVAL;
-    const bool cores = (flags & NSC_GAT_CORESIDENT) != 0;
+    if (flags & ~(uint32_t)(NSC_GAT_CORESIDENT | NSC_GAT_SHARED_B)) return NSC_EINVAL;
+    if ((flags & NSC_GAT_SHARED_B) && !(flags & NSC_GAT_CORESIDENT)) return NSC_EINVAL;
+    const int cores = (flags & NSC_GAT_CORESIDENT) ? ((flags & NSC_GAT_SHARED_B) ? 2 : 1) : 0;
     int stt = check_model(m);
     if (stt != NSC_OK) return stt;
     if (!g || g->n_nodes < 0) return NSC_EINVAL;

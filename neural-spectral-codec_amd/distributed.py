@@ -231,7 +231,8 @@ class ShardedDescriptorPath:
     def _pipe_setup(self, device):
         inner = getattr(self.gnn, "gnn", self.gnn)
         if hasattr(inner, "coresident"):
-            inner.coresident = bool(self.coresident_gnn)     # the kernel set this path asked for, whatever was set before
+            # the kernel set this path asked for, whatever was set before (True, False or "shared_b")
+            inner.coresident = self.coresident_gnn if self.coresident_gnn == "shared_b" else bool(self.coresident_gnn)
         n_local, d = self.hi - self.lo, int(getattr(self.encoder, "output_dim", 800))
         nb = self._PIPE_BUFFERS
         if device.type == "cuda":
@@ -383,7 +384,7 @@ class ShardedDescriptorPath:
         key = (x.data_ptr(), tuple(x.shape),
                tuple((t.data_ptr(), t._version) for t in (inner._live_tensors() if hasattr(inner, "_live_tensors")
                                                           else list(inner.parameters()) + list(inner.buffers()))),
-               bool(getattr(inner, "coresident", False)))
+               getattr(inner, "coresident", False))
         ent = self._gnn_graphs.get(slot)
         if ent is not None and ent[0] == key:
             ent[1].replay()

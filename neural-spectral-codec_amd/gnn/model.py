@@ -189,7 +189,8 @@ class SpectralGNN(nn.Module):
         self._csr_cache = {}
         self._struct_cache = None          # (key, GatModel, folded tensor)
         # True: launch the LDS-free, low-VGPR kernel set (NSC_GAT_CORESIDENT) whose workgroups fit beside a
-        # resident encoder grid -- used by distributed.ShardedDescriptorPath(pipeline=True).  Same output.
+        # resident encoder grid -- used by distributed.ShardedDescriptorPath(pipeline=True).  "shared_b": that set with
+        # the small-LDS GEMMs (NSC_GAT_SHARED_B).  Same output, bit for bit.
         self.coresident = False
         self._seed_dev = None              # device int64[1]: dropout seed read by the kernels at run time (captured steps)
 
@@ -343,7 +344,8 @@ class SpectralGNN(nn.Module):
         with torch.cuda.device(dev):
             st = L.nsc_gat_forward_ex(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
                                       _lib.ptr(out), _lib.ptr(alpha), _lib.ptr(ws), nbytes,
-                                      1 if getattr(self, "coresident", False) else 0, _lib.stream_ptr(dev))
+                                      {False: 0, True: 1, "shared_b": 3}[getattr(self, "coresident", False)],
+                                      _lib.stream_ptr(dev))
         _lib.check(st, "nsc_gat_forward_ex")
         return out, alpha, csr
 

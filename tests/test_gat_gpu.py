@@ -130,8 +130,10 @@ def test_coresident_variant_is_bit_identical(n, edge_dim):
         a = m(g)
         m.gnn.coresident = True
         b = m(g)
+        m.gnn.coresident = "shared_b"                 # NSC_GAT_SHARED_B: 64 x 64 tiles, weight block shared through 10 KB of LDS
+        c = m(g)
         m.gnn.coresident = False
-    assert torch.equal(a, b)
+    assert torch.equal(a, b) and torch.equal(a, c)
     _check(b, m, g)
 
 
@@ -159,7 +161,9 @@ def test_coresident_other_dims():
         a = m(g)
         m.gnn.coresident = True
         b = m(g)
-    assert torch.equal(a, b)
+        m.gnn.coresident = "shared_b"
+        c = m(g)
+    assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_pipelined_path_matches_serial():

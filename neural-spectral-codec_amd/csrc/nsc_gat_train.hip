@@ -201,22 +201,19 @@ __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part
     }
 }
 
-// The two passes in ONE launch (round 3: the 19 partial/final pairs of a training step were a fifth of its kernel
-// time and a quarter of its launches).  Every workgroup writes its float64 partials; the LAST one of a column block to
-// arrive -- a ticket from a device-scope atomic, partials released before it and acquired after it -- sums them in the
-// same fixed order as before: the result does not depend on which workgroup is last.  The ticket counter is reset by
-// that workgroup, so one zeroed counter array per C call serves every reduction of the call.
-__global__ __launch_bounds__(256) void colreduce_fused_kernel(const float *__restrict__ P, const float *__restrict__ w,
-                                                              const float *__restrict__ Q, const float *__restrict__ qm,
-                                                              const float *__restrict__ qs, int N, int C,
-                                                              int rows_per_block, double *__restrict__ part,
-                                                              unsigned *__restrict__ tickets, ColFinal f)
+// Pass 1: every workgroup reduces its rows of a 64-column block to float64 partials.
+// (Round 3 measured both passes fused into ONE launch -- the last workgroup of a column block to arrive, by a device-scope
+// ticket, finishing the sum: the release / acquire fences it needs are an L2 write-back + invalidate on an 8-XCD part, and the
+// fused kernel took 26.5 us where the two launches take 8 + 5.5 -- the whole training step got slower by a third of its kernel
+// time.  Two launches it stays; inside a captured hipGraph the second launch costs about a microsecond.)
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__restrict__ P, const float *__restrict__ w,
+                                                                const float *__restrict__ Q, const float *__restrict__ qm,
+                                                                const float *__restrict__ qs, int N, int C,
+                                                                int rows_per_block, double *__restrict__ part)
 {
     __shared__ double sa[256], sb[256];
-    __shared__ unsigned last;
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
-    const int R = gridDim.y;
     const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
     double a = 0.0, b = 0.0;
     if (c < C) {
@@ -239,22 +236,14 @@ __global__ __launch_bounds__(256) void colreduce_fused_kernel(const float *__res
         part[((long long)blockIdx.y * C + c) * 2] = a;
         part[((long long)blockIdx.y * C + c) * 2 + 1] = b;
     }
-    if (R == 1) {                                         // a single row block: it is the last one by construction
-        __syncthreads();
-        colreduce_finish(part, 1, C, c, cx, ry, sa, sb, f);
-        return;
-    }
-    __threadfence();                                      // release: this workgroup's partials are visible device-wide
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t == (unsigned)R - 1u);
-        if (last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next reduction
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();                                      // acquire: the other workgroups' partials, not stale cache lines
-    colreduce_finish(part, R, C, c, cx, ry, sa, sb, f);
+}
+
+// Pass 2: the R partial rows of a 64-column block, summed in fixed order (deterministic), then the finish (ColFinal).
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C, ColFinal f)
+{
+    __shared__ double sa[256], sb[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    colreduce_finish(part, R, C, blockIdx.x * 64 + cx, cx, ry, sa, sb, f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,13 +673,12 @@ __global__ __launch_bounds__(256) void triplet_reduce_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------
 constexpr int SPLITK_SLABS = 16;
 constexpr int COLRED_MAXR = 64;
-constexpr int COLRED_TICKETS = 64;        // column blocks of 64: up to 4 096 columns
 
 struct TrainWs {
     // saved by the forward
     size_t z0, mean0, invstd0, h, g, a_src, a_dst, alpha, y, mean, invstd, vvec;
     // backward scratch
-    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, tickets, total;
+    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, total;
     size_t nh, nn, hh, nz;
 };
 
@@ -727,7 +715,6 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
     w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);
     w.colpart = o; o += align256((size_t)COLRED_MAXR * std::max(std::max(H, m->out_dim), m->in_dim) * 2 * 8);
-    w.tickets = o; o += align256(COLRED_TICKETS * sizeof(unsigned));   // one per 64-column block, zero between reductions
     w.total = o;
     return w;
 }
@@ -751,7 +738,7 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
 }
 
 void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
-               int N, int C, double *part, unsigned *tickets, int mode, float eps, float momentum, float *out_a,
+               int N, int C, double *part, int mode, float eps, float momentum, float *out_a,
                float *out_b, float *run_mean, float *run_var)
 {
     int R = (N + 63) / 64;
@@ -759,8 +746,8 @@ void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, c
     if (R < 1) R = 1;
     const int rows = (N + R - 1) / R;
     const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var};
-    hipLaunchKernelGGL(colreduce_fused_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part,
-                       tickets, f);
+    hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f);
 }
 
 inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
@@ -771,7 +758,6 @@ int check_train(const NscGatModel *m, const NscGraph *g)
     if (m->n_layers < 1 || m->n_layers > NSC_GAT_MAX_LAYERS) return NSC_EUNSUPPORTED;
     if (m->hidden < 16 || m->hidden > 1024 || (m->hidden & 15)) return NSC_EUNSUPPORTED;
     if (m->in_dim < 16 || (m->in_dim & 15) || m->out_dim < 4 || (m->out_dim & 3)) return NSC_EUNSUPPORTED;
-    if (m->in_dim > 64 * COLRED_TICKETS || m->out_dim > 64 * COLRED_TICKETS) return NSC_EUNSUPPORTED;   // column-reduction tickets
     if (m->edge_dim < 0 || m->edge_dim > NSC_GAT_MAX_EDGE_DIM) return NSC_EUNSUPPORTED;
     if (m->residual && m->in_dim != m->out_dim && (!m->res_w || !m->res_b)) return NSC_EINVAL;   // model.py:91-94
     if (!g->row_ptr || !g->src || !g->eid) return NSC_EINVAL;
@@ -823,15 +809,13 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
     char *b = static_cast<char *>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
-    unsigned *tickets = reinterpret_cast<unsigned *>(b + w.tickets);
-    if (hipMemsetAsync(tickets, 0, COLRED_TICKETS * sizeof(unsigned), st) != hipSuccess) return NSC_ELAUNCH;
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
     const int upd = cfg->update_running_stats;
 
     // input_proj (bias) -> z0 ; BatchNorm(batch stats) ; ReLU                 model.py:116-118
     gemm<false, false>(st, x, m->in_dim, m->in_w, m->in_dim, N, H, m->in_dim, F(w.z0), H, m->in_b, 0, 1, nullptr);
-    colreduce(st, F(w.z0), nullptr, F(w.z0), nullptr, nullptr, N, H, colpart, tickets, 1, m->bn_eps, cfg->bn_momentum,
+    colreduce(st, F(w.z0), nullptr, F(w.z0), nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum,
               F(w.mean0), F(w.invstd0), upd ? const_cast<float *>(m->in_bn_mean) : nullptr,
               upd ? const_cast<float *>(m->in_bn_var) : nullptr);
     hipLaunchKernelGGL(bn_act_kernel, dim3(blocks(NH)), dim3(256), 0, st, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
@@ -856,7 +840,7 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
         a.slope = m->negative_slope; a.p = cfg->dropout_p; a.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; a.stream = 100u + l;
         a.N = N; a.H = H; a.edge_dim = m->edge_dim;
         hipLaunchKernelGGL(agg_train_kernel, dim3((N + 3) / 4), dim3(256), 0, st, a);
-        colreduce(st, y, nullptr, y, nullptr, nullptr, N, H, colpart, tickets, 1, m->bn_eps, cfg->bn_momentum, mean, invstd,
+        colreduce(st, y, nullptr, y, nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum, mean, invstd,
                   upd ? const_cast<float *>(Ly.bn_mean) : nullptr, upd ? const_cast<float *>(Ly.bn_var) : nullptr);
         const int act = (l < L - 1);                                           // model.py:135-137
         const float *resid = (m->residual && l > 0 && l < L - 1) ? hin : nullptr;   // model.py:140-141
@@ -890,22 +874,20 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     char *b = static_cast<char *>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
-    unsigned *tickets = reinterpret_cast<unsigned *>(b + w.tickets);
-    if (hipMemsetAsync(tickets, 0, COLRED_TICKETS * sizeof(unsigned), st) != hipSuccess) return NSC_ELAUNCH;
     float *slabs = F(w.slabs);
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
     const int splits = N >= 512 ? SPLITK_SLABS : 1;
 
     // output_proj: out = h_L W_out^T + b (+ x)
-    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, tickets, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr);
+    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr);
     gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, 0, splits, slabs);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
     gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, nullptr);   // dh_L = dOut W_out
     const bool res_id = m->residual && Din == Dout, res_proj = m->residual && Din != Dout;
     if (res_proj) {                // residual_proj: dW_res = dOut^T x, db_res = colsum dOut      model.py:147-149
         if (!gr->res_w || !gr->res_b) return NSC_EINVAL;
-        colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, tickets, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr);
+        colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr);
         gemm<true, true>(st, grad_out, Dout, x, Din, Dout, Din, N, gr->res_w, Din, nullptr, 0, splits, slabs);
     }
     if (gr->x) {
@@ -933,13 +915,13 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         // h_{l+1} = drop(relu(bn(y))) [+ h_l]  ->  dV, BatchNorm backward -> dY (in place in dv)
         hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
                            act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, NH, H, dv);
-        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, tickets, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
+        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
         if (hipMemcpyAsync(Gl.bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
         if (hipMemcpyAsync(Gl.bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, y, mean, invstd, Ly.bn_w, s1, s2, NH, H, N, dv);
         float *dY = dv;
         // conv bias
-        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr);
+        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr);
         // attention backward
         AttBwdA A;
         A.row_ptr = g->row_ptr; A.src = g->src; A.eid = g->eid;
@@ -957,8 +939,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         Bk.p = cfg->dropout_p; Bk.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; Bk.stream = 100u + l; Bk.N = N; Bk.H = H;
         hipLaunchKernelGGL(att_bwd_source_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Bk);
         // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
-        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr);
-        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr);
+        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr);
+        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr);
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
             if (use_edge) {
                 hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,
@@ -982,12 +964,12 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     float *dv = F(w.dv), *s1 = F(w.s1), *s2 = F(w.s2);
     hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
                        m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, NH, H, dv);
-    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, tickets, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
+    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
     if (hipMemcpyAsync(gr->in_bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
     if (hipMemcpyAsync(gr->in_bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, s1, s2,
                        NH, H, N, dv);
-    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, tickets, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr);
+    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr);
     gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, 0, splits, slabs);
     if (gr->x) {   // + dZ0 W_in
         gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, nullptr);

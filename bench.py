@@ -178,7 +178,7 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
             "flop_per_forward": GAT_FLOP_PER_NODE * 4541, "forward_us": gat[4541],
             "forward_us_at_step_size": gat[n_local], "traffic": None,
             "note": "whole forward (8 launches) by HIP events; per-kernel durations and the MFMA counters "
-                    "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32) are in profiles/r02_gat_n4541_*",
+                    "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32) are in profiles/r03_gat_n4541_*",
         }
         # the three point orders interleaved, so that clock drift between "then" and "now" cannot pass for an effect of the
         # order: 5 rounds of 8 launches each, median per order

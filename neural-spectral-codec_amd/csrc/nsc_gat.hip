@@ -183,7 +183,7 @@ struct GemmEpi {
     int ldr;
     float *aux0, *aux1;                             // columns n_main, n_main+1 (M each), nullable
 #ifdef NSC_DEV_TUNING
-    int dev;                                        // ablation bits (tools/r02_gat_ab2.sh): 1 no MFMAs, 2 no refills, 4 no LDS operand reads
+    int dev;                                        // ablation bits (development builds, NSC_TUNE_GEMM_ABL): 1 no MFMAs, 2 no refills, 4 no LDS operand reads
 #endif
 };
 

@@ -198,3 +198,49 @@ def test_pipelined_path_matches_serial():
         torch.cuda.synchronize()
     assert torch.equal(d, want[-1][0]) and torch.equal(e, want[-1][1])
     m.gnn.coresident = False
+
+
+@pytest.mark.parametrize("opts", [dict(gnn_graph=True), dict(gnn_streams=2), dict(gnn_graph=True, gnn_streams=2, encoder_streams=1)])
+def test_pipelined_path_options_match_serial(opts):
+    """The pipelined step's options -- the GNN forward replayed as a captured hipGraph per rotating buffer, the GNN
+    passes of consecutive batches on two streams, one or two encoder streams -- change scheduling only: every step's
+    results equal the one-stream path's, bit for bit, over more steps than rotating buffers (a captured forward is keyed
+    on its input buffer and the model's parameter versions: a weight update in between must recapture)."""
+    from neural_spectral_codec_amd import distributed as nd, synth
+    from neural_spectral_codec_amd.encoding import SpectralEncoder
+    n = 96
+    enc = SpectralEncoder(n_elevation=16).to("cuda")
+    m = _model()
+    poses = synth.make_pose_chain(n, 0)
+    batches = [synth.make_clouds_device(n, 3000, "cuda", seed=s) for s in range(1, 11)]
+    serial = nd.ShardedDescriptorPath(enc, m, n, poses)
+    piped = nd.ShardedDescriptorPath(enc, m, n, poses, pipeline=True, **opts)
+    with torch.no_grad():
+        m.gnn.coresident = False
+        want = [tuple(t.clone() for t in serial.step(b)) for b in batches]
+        got = []
+        for b in batches:
+            d, e = piped.step(b)
+            torch.cuda.current_stream().wait_event(piped.last_event)
+            got.append((d.clone(), e.clone()))
+        piped.synchronize()
+        torch.cuda.synchronize()
+        for (wd, we), (gd, ge) in zip(want, got):
+            assert torch.equal(wd, gd) and torch.equal(we, ge)
+        if opts.get("gnn_graph"):
+            assert len(piped._gnn_graphs) == nd.ShardedDescriptorPath._PIPE_BUFFERS      # one capture per rotating buffer
+            # new weights: the captures are stale and must not be replayed
+            m.gnn.output_proj.bias.add_(0.25)
+            m.gnn.coresident = False
+            want2 = [tuple(t.clone() for t in serial.step(b)) for b in batches[:6]]
+            got2 = []
+            for b in batches[:6]:
+                d, e = piped.step(b)
+                torch.cuda.current_stream().wait_event(piped.last_event)
+                got2.append((d.clone(), e.clone()))
+            piped.synchronize()
+            torch.cuda.synchronize()
+            for (wd, we), (gd, ge) in zip(want2, got2):
+                assert torch.equal(wd, gd) and torch.equal(we, ge)
+            assert not torch.equal(want2[0][1], want[0][1])
+    m.gnn.coresident = False

@@ -234,12 +234,17 @@ typedef struct NscGatTrainCfg {
     float    bn_momentum;          /* 0.1 (nn.BatchNorm1d default) */
     uint64_t seed;                 /* counter-based dropout masks: same seed in forward and backward */
     int32_t  update_running_stats; /* 1: running_mean / running_var of the model are updated IN PLACE */
+    int32_t  accumulate_grads;     /* nsc_gat_backward: 1 = every PARAMETER gradient is ADDED to what its NscGatGrads buffer
+                                      holds (gradient accumulation over the batches of an optimizer step, trainer.py:207-221,
+                                      without a pass of axpy kernels behind the backward); 0 = overwritten.  grads->x is
+                                      always overwritten */
     const uint64_t *seed_dev;      /* nullable DEVICE pointer: when set, the kernels read the seed from this word at run
                                       time instead of `seed` -- a training step captured into a hipGraph then replays
                                       with a fresh mask per step (the caller rewrites the word between replays) */
 } NscGatTrainCfg;
 
-typedef struct NscGatGradLayer {   /* device buffers shaped like the NscGatLayer parameters; overwritten */
+typedef struct NscGatGradLayer {   /* device buffers shaped like the NscGatLayer parameters; overwritten, or added to
+                                      with NscGatTrainCfg.accumulate_grads */
     float *lin_w, *att_src, *att_dst, *lin_edge_w, *att_edge, *bias, *bn_w, *bn_b;
 } NscGatGradLayer;
 

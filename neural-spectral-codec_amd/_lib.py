@@ -59,7 +59,7 @@ class Graph(C.Structure):
 class GatTrainCfg(C.Structure):
     """struct NscGatTrainCfg"""
     _fields_ = [("dropout_p", C.c_float), ("bn_momentum", C.c_float), ("seed", C.c_uint64),
-                ("update_running_stats", C.c_int32), ("seed_dev", C.c_void_p)]
+                ("update_running_stats", C.c_int32), ("accumulate_grads", C.c_int32), ("seed_dev", C.c_void_p)]
 
 
 class MineParams(C.Structure):

@@ -149,13 +149,13 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(const float *__restrict__
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ part, int S, long long MN,
-                                                          float *__restrict__ out)
+                                                          float *__restrict__ out, int accumulate)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= MN) return;
     float s = 0.0f;
     for (int z = 0; z < S; ++z) s += part[(long long)z * MN + i];     // fixed order: deterministic
-    out[i] = s;
+    out[i] = accumulate ? out[i] + s : s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,6 +170,7 @@ struct ColFinal {
     int mode, N;
     float eps, momentum;
     float *out_a, *out_b, *run_mean, *run_var;
+    int acc_a, acc_b;          // mode 0: add to what out_a / out_b hold (gradient accumulation) instead of overwriting
 };
 
 __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part, int R, int C, int c, int cx, int ry,
@@ -185,8 +186,8 @@ __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part
     a = (sa[cx] + sa[64 + cx]) + (sa[128 + cx] + sa[192 + cx]);
     b = (sb[cx] + sb[64 + cx]) + (sb[128 + cx] + sb[192 + cx]);
     if (f.mode == 0) {
-        if (f.out_a) f.out_a[c] = (float)a;
-        if (f.out_b) f.out_b[c] = (float)b;
+        if (f.out_a) f.out_a[c] = f.acc_a ? f.out_a[c] + (float)a : (float)a;
+        if (f.out_b) f.out_b[c] = f.acc_b ? f.out_b[c] + (float)b : (float)b;
     } else {
         const double mean = a / f.N;
         double var = b / f.N - mean * mean;
@@ -554,16 +555,26 @@ __global__ __launch_bounds__(256) void edge_vec_kernel(const float *__restrict__
 }
 __global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const float *__restrict__ w_edge, const float *__restrict__ att_edge,
                                                            const float *__restrict__ dv, int H, int edge_dim,
-                                                           float *__restrict__ dw_edge, float *__restrict__ datt_edge)
+                                                           float *__restrict__ dw_edge, float *__restrict__ datt_edge,
+                                                           int accumulate)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= H) return;
     float s = 0.0f;
     for (int d = 0; d < edge_dim; ++d) {
-        dw_edge[(long long)c * edge_dim + d] = dv[d] * att_edge[c];
+        const float gw = dv[d] * att_edge[c];
+        dw_edge[(long long)c * edge_dim + d] = accumulate ? dw_edge[(long long)c * edge_dim + d] + gw : gw;
         s = __builtin_fmaf(dv[d], w_edge[(long long)c * edge_dim + d], s);
     }
-    datt_edge[c] = s;
+    datt_edge[c] = accumulate ? datt_edge[c] + s : s;
+}
+
+// dst = src, or dst += src (gradient accumulation) for a short vector
+__global__ __launch_bounds__(256) void vec_store_kernel(float *__restrict__ dst, const float *__restrict__ src, int n,
+                                                        int accumulate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
 }
 
 // transposed CSR (entries grouped by source) from the forward CSR
@@ -733,19 +744,19 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
         hipLaunchKernelGGL((gemm_gen_kernel<AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, K, kchunk, slabs,
                            N, (long long)M * N, static_cast<const float *>(nullptr), 0);
         const long long MN = (long long)M * N;      // requires ldc == N
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
     }
 }
 
 void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
                int N, int C, double *part, int mode, float eps, float momentum, float *out_a,
-               float *out_b, float *run_mean, float *run_var)
+               float *out_b, float *run_mean, float *run_var, int acc_a = 0, int acc_b = 0)
 {
     int R = (N + 63) / 64;
     if (R > COLRED_MAXR) R = COLRED_MAXR;
     if (R < 1) R = 1;
     const int rows = (N + R - 1) / R;
-    const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var};
+    const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var, acc_a, acc_b};
     hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part);
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f);
 }
@@ -878,17 +889,20 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
     const int splits = N >= 512 ? SPLITK_SLABS : 1;
+    // NscGatTrainCfg.accumulate_grads: every PARAMETER gradient is added to what its buffer holds (gradient accumulation
+    // over the batches of an optimizer step without a pass of axpy kernels behind the backward); gr->x is always overwritten
+    const int acc = cfg->accumulate_grads ? 1 : 0;
 
     // output_proj: out = h_L W_out^T + b (+ x)
-    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr);
-    gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, 0, splits, slabs);
+    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr, acc);
+    gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, acc, splits, slabs);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
     gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, nullptr);   // dh_L = dOut W_out
     const bool res_id = m->residual && Din == Dout, res_proj = m->residual && Din != Dout;
     if (res_proj) {                // residual_proj: dW_res = dOut^T x, db_res = colsum dOut      model.py:147-149
         if (!gr->res_w || !gr->res_b) return NSC_EINVAL;
-        colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr);
-        gemm<true, true>(st, grad_out, Dout, x, Din, Dout, Din, N, gr->res_w, Din, nullptr, 0, splits, slabs);
+        colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr, acc);
+        gemm<true, true>(st, grad_out, Dout, x, Din, Dout, Din, N, gr->res_w, Din, nullptr, acc, splits, slabs);
     }
     if (gr->x) {
         // gradient wrt the input features through the residual connection: dOut itself (identity residual),
@@ -916,12 +930,12 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
                            act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, NH, H, dv);
         colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
-        if (hipMemcpyAsync(Gl.bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
-        if (hipMemcpyAsync(Gl.bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+        hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, Gl.bn_b, s1, H, acc);
+        hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, Gl.bn_w, s2, H, acc);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, y, mean, invstd, Ly.bn_w, s1, s2, NH, H, N, dv);
         float *dY = dv;
         // conv bias
-        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr);
+        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr, acc);
         // attention backward
         AttBwdA A;
         A.row_ptr = g->row_ptr; A.src = g->src; A.eid = g->eid;
@@ -939,8 +953,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         Bk.p = cfg->dropout_p; Bk.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; Bk.stream = 100u + l; Bk.N = N; Bk.H = H;
         hipLaunchKernelGGL(att_bwd_source_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Bk);
         // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
-        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr);
-        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr);
+        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr, acc);
+        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr, acc);
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
             if (use_edge) {
                 hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,
@@ -948,14 +962,14 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
                 hipLaunchKernelGGL(edge_term_bwd_final_kernel, dim3(1), dim3(64), 0, st, colpart, EDGE_BWD_WGS, m->edge_dim,
                                    F(w.dvvec));
                 hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(blocks(H)), dim3(256), 0, st, Ly.lin_edge_w, Ly.att_edge, F(w.dvvec),
-                                   H, m->edge_dim, Gl.lin_edge_w, Gl.att_edge);
-            } else {
+                                   H, m->edge_dim, Gl.lin_edge_w, Gl.att_edge, acc);
+            } else if (!acc) {                      // no edge term in this forward: zero gradient (nothing to add when accumulating)
                 if (hipMemsetAsync(Gl.lin_edge_w, 0, (size_t)H * m->edge_dim * 4, st) != hipSuccess) return NSC_ELAUNCH;
                 if (hipMemsetAsync(Gl.att_edge, 0, (size_t)H * 4, st) != hipSuccess) return NSC_ELAUNCH;
             }
         }
         // g = h_l W^T :  dW = dG^T h_l ,  dh_l = dG W (+ residual path)
-        gemm<true, true>(st, dG, H, hin, H, H, H, N, Gl.lin_w, H, nullptr, 0, splits, slabs);
+        gemm<true, true>(st, dG, H, hin, H, H, H, N, Gl.lin_w, H, nullptr, acc, splits, slabs);
         gemm<false, true>(st, dG, H, Ly.lin_w, H, N, H, H, dh_prev, H, nullptr, 0, 1, nullptr);
         if (has_res) hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh_prev, dh, NH);
         float *t = dh; dh = dh_prev; dh_prev = t;
@@ -965,12 +979,12 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
                        m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, NH, H, dv);
     colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
-    if (hipMemcpyAsync(gr->in_bn_b, s1, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
-    if (hipMemcpyAsync(gr->in_bn_w, s2, (size_t)H * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+    hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, gr->in_bn_b, s1, H, acc);
+    hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, gr->in_bn_w, s2, H, acc);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, s1, s2,
                        NH, H, N, dv);
-    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr);
-    gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, 0, splits, slabs);
+    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr, acc);
+    gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, acc, splits, slabs);
     if (gr->x) {   // + dZ0 W_in
         gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, nullptr);
     }

@@ -137,7 +137,11 @@ class _GatTrainFunction(torch.autograd.Function):
         m = gnn._train_struct()
         g = csr.struct()
         params = gnn._train_params()
-        grads = [torch.empty_like(p) for p in params]
+        # GNNTrainer's steps: the kernels ADD into the existing .grad tensors (NscGatTrainCfg.accumulate_grads) and autograd
+        # gets no parameter gradients back -- no AccumulateGrad axpy per parameter (30 small kernels per batch)
+        direct = bool(getattr(gnn, "_direct_grads", False)) and all(p.grad is not None and p.grad.is_contiguous() for p in params)
+        grads = [p.grad for p in params] if direct else [torch.empty_like(p) for p in params]
+        ctx.cfg.accumulate_grads = 1 if direct else 0
         gs = _lib.GatGrads()
         it = iter(grads)
         gs.in_w, gs.in_b = next(it).data_ptr(), next(it).data_ptr()
@@ -160,6 +164,8 @@ class _GatTrainFunction(torch.autograd.Function):
                                     _lib.stream_ptr(dev))
         _lib.check(st, "nsc_gat_backward")
         ctx.ws = None
+        if direct:
+            return (None, gx, None, None, None) + (None,) * len(grads)
         return (None, gx, None, None, None, *grads)
 
 
@@ -193,6 +199,7 @@ class SpectralGNN(nn.Module):
         # the small-LDS GEMMs (NSC_GAT_SHARED_B).  Same output, bit for bit.
         self.coresident = False
         self._seed_dev = None              # device int64[1]: dropout seed read by the kernels at run time (captured steps)
+        self._direct_grads = False         # backward adds straight into the parameters' .grad tensors (GNNTrainer's steps)
 
     # -- plumbing ---------------------------------------------------------------------------
     def __getstate__(self):
@@ -202,6 +209,7 @@ class SpectralGNN(nn.Module):
         state["_struct_cache"] = None
         state["_train_struct_cache"] = None
         state["_seed_dev"] = None
+        state["_direct_grads"] = False
         return state
 
     def _csr(self, data, use_edge_attr: bool) -> GraphCSR:

@@ -91,7 +91,8 @@ class GNNTrainer:
     def __init__(self, model: nn.Module, device: str = 'cuda', learning_rate: float = 5e-4,
                  weight_decay: float = 1e-5, margin: float = 0.1, checkpoint_dir: Optional[str] = None,
                  log_interval: int = 10, use_multi_gpu: bool = True, patience: int = 10,
-                 batch_size: int = 1024, accumulation_steps: int = 4, use_graph: bool = True):
+                 batch_size: int = 1024, accumulation_steps: int = 4, use_graph: bool = True,
+                 direct_grads: bool = True):
         self.model = model.to(device)
         self.device = device
         self.patience = patience                                                                      # :112
@@ -101,6 +102,8 @@ class GNNTrainer:
         self.batch_size, self.accumulation_steps = batch_size, accumulation_steps
         # replay the per-batch step (forward + loss + backward) as a captured hipGraph from its second occurrence on
         self.use_graph = use_graph
+        # the backward adds into the existing .grad tensors itself instead of handing gradients to autograd's AccumulateGrad
+        self.direct_grads = direct_grads
         self._captured, self._seen_once, self._capture_failed = {}, set(), False
         # the reference creates 'checkpoints/' eagerly (:123-124); here the directory appears with the first save
         self.checkpoint_dir = Path(checkpoint_dir if checkpoint_dir is not None else 'checkpoints')
@@ -252,9 +255,19 @@ class GNNTrainer:
 
     # -- the per-batch step, captured --------------------------------------------------------------------------
     def _eager_step(self, graph, ia, ip, in_, scale):
-        embeddings = self.model(graph)                                                        # :205
-        loss = self.criterion.forward_indexed(embeddings, ia, ip, in_, scale=scale)           # :207-212
-        loss.backward()                                                                       # :213
+        inner = getattr(self.model, "gnn", self.model)
+        # the backward adds straight into the .grad tensors (they exist: zero_grad keeps them) -- no AccumulateGrad pass
+        direct = (self.direct_grads and hasattr(inner, "_direct_grads")
+                  and all(p.grad is not None for p in self.model.parameters() if p.requires_grad))
+        if direct:
+            inner._direct_grads = True
+        try:
+            embeddings = self.model(graph)                                                    # :205
+            loss = self.criterion.forward_indexed(embeddings, ia, ip, in_, scale=scale)       # :207-212
+            loss.backward()                                                                   # :213
+        finally:
+            if direct:
+                inner._direct_grads = False
         return loss.detach()
 
     def _captured_step(self, graph, bt, scale, bt_dev=None):

@@ -444,17 +444,21 @@ def test_captured_training_step_matches_eager():
     rng = np.random.default_rng(2)
     trip = np.stack([rng.integers(0, n, 1800), rng.integers(0, n, 1800), rng.integers(0, n, 1800)], 1)   # 7 x 256 + 8
     outs = []
-    for use_graph in (False, True):
+    # (eager, gradients through autograd's AccumulateGrad) / (eager, the backward adds into .grad itself:
+    # NscGatTrainCfg.accumulate_grads) / (captured, the same)
+    for use_graph, direct in ((False, False), (False, True), (True, True)):
         m, g, _ = _setup(n, 2)
         tr = GNNTrainer(m, device="cuda", learning_rate=5e-4, weight_decay=1e-5, margin=0.1, batch_size=256,
-                        accumulation_steps=4, use_graph=use_graph)
+                        accumulation_steps=4, use_graph=use_graph, direct_grads=direct)
         loss = tr.train_batches(g, trip)
         assert bool(tr._captured) == use_graph and not tr._capture_failed
         outs.append((loss, {k: v.detach().cpu().clone() for k, v in m.gnn.named_parameters()},
                      m.gnn.input_norm.running_mean.cpu().clone(), int(m.gnn.input_norm.num_batches_tracked)))
-    (l0, p0, rm0, nb0), (l1, p1, rm1, nb1) = outs
-    assert nb0 == nb1 == 8
-    assert abs(l0 - l1) <= 1e-5 * abs(l0) + 1e-7
+    (l0, p0, rm0, nb0), (l2, p2, rm2, nb2), (l1, p1, rm1, nb1) = outs
+    assert nb0 == nb1 == nb2 == 8
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) + 1e-7 and abs(l0 - l2) <= 1e-5 * abs(l0) + 1e-7
+    for k in p0:                                             # in-kernel accumulation == autograd accumulation
+        assert (p0[k] - p2[k]).abs().max().item() <= 4.2 * 5e-4, k
     # (after the first optimizer step the two runs' weights differ by +-lr where a gradient is rounding noise, see below;
     #  rows of x sum to 1, so the input projection's batch mean may move by a few lr)
     assert torch.allclose(rm0, rm1, rtol=0, atol=4 * 5e-4)

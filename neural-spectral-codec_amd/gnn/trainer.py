@@ -97,14 +97,7 @@ class GNNTrainer:
         self.device = device
         self.patience = patience                                                                      # :112
         self.epochs_without_improvement = 0
-        # :115-119 Adam(lr, L2 weight decay).  On a HIP device torch's fused implementation (one multi-tensor kernel for the
-        # 30 parameter tensors instead of ~10 foreach kernels: same arithmetic); the default implementation elsewhere
-        adam_kw = dict(lr=learning_rate, weight_decay=weight_decay)
-        try:
-            on_gpu = torch.device(device).type == "cuda" and all(p.is_cuda for p in model.parameters())
-            self.optimizer = optim.Adam(model.parameters(), fused=True, **adam_kw) if on_gpu else optim.Adam(model.parameters(), **adam_kw)
-        except (RuntimeError, TypeError, ValueError):
-            self.optimizer = optim.Adam(model.parameters(), **adam_kw)
+        self.optimizer = optim.Adam(model.parameters(), lr=learning_rate, weight_decay=weight_decay)  # :115-119
         self.criterion = TripletLoss(margin=margin)                                                   # :121
         self.batch_size, self.accumulation_steps = batch_size, accumulation_steps
         # replay the per-batch step (forward + loss + backward) as a captured hipGraph from its second occurrence on

@@ -370,6 +370,12 @@ class GNNTrainer:
                 nd.all_reduce_gradients(params)                            # one 2.46 MB RCCL all-reduce
                 self.optimizer.step()
                 self.optimizer.zero_grad(set_to_none=False)
+                # the eval-mode forward caches folded attention vectors keyed on the parameters' version counters; an
+                # optimizer that writes through a multi-tensor kernel need not bump them (torch's fused Adam does not:
+                # measured, round 3) -- drop the cache explicitly
+                inner_ = getattr(self.model, "gnn", self.model)
+                if hasattr(inner_, "_struct_cache"):
+                    inner_._struct_cache = None
         if not losses:
             return 0.0
         return float(torch.stack(losses).mean().item() * self.accumulation_steps)

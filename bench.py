@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--calibrate", action="store_true", help=argparse.SUPPRESS)      # time all three step implementations
     ap.add_argument("--calibrate2", action="store_true", help=argparse.SUPPRESS)     # the N > 1 choice (pipelined2 / serial) at N = 1
     ap.add_argument("--gnn-streams", type=int, default=1, help=argparse.SUPPRESS)    # GNN passes alternate over this many streams
-    ap.add_argument("--gnn-graph", type=int, default=0, help=argparse.SUPPRESS)      # 1: replay the GNN forward as a hipGraph
+    ap.add_argument("--gnn-graph", type=int, default=-1, help=argparse.SUPPRESS)     # GNN forward as a replayed hipGraph: 1 / 0, -1 = the path's default
     ap.add_argument("--gnn-nodes", type=int, default=0, help=argparse.SUPPRESS)      # DIAGNOSTIC: GNN over the first n keyframes only
     ap.add_argument("--no-gnn", action="store_true", help=argparse.SUPPRESS)         # DIAGNOSTIC (not the metric): identity in place of the GNN
     args = ap.parse_args()
@@ -313,7 +313,7 @@ def main():
         gnn_ = _NoGnn() if args.no_gnn else (_PartGnn(args.gnn_nodes) if args.gnn_nodes else model)
         p_ = nd.ShardedDescriptorPath(enc, gnn_, n_total, poses, pipeline=pipelined,
                                       encoder_streams=enc_streams,
-                                      gnn_streams=args.gnn_streams, gnn_graph=bool(args.gnn_graph))
+                                      gnn_streams=args.gnn_streams, gnn_graph=None if args.gnn_graph < 0 else bool(args.gnn_graph))
         if not pipelined:
             p_.encoder = _Enc
         return p_

@@ -217,9 +217,12 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
  * 5 x 80 VGPRs): issue it on its own stream to run the GNN of batch k under the encoders of batches k+1, k+2.
  * NSC_GAT_SHARED_B (with NSC_GAT_CORESIDENT): the GEMMs use 64 x 64 tiles that share the weight block through 10 KB of LDS
  * (two such workgroups fit in the 20 KB a CU has left beside five encoder workgroups): fewer LDS-pipe and L1 operations
- * per FLOP.  Bit-identical output in every combination. */
+ * per FLOP.  NSC_GAT_LDS_TILED (alone): the stand-alone forward with the round-2 GEMMs (register-staged 16/32/64 x 64 tiles)
+ * instead of the default LDS-DMA, wave-specialised GEMM of round 3 -- kept for A/B measurements and as the fall-back when
+ * that kernel cannot run (unaligned operands, LDS opt-in refused).  Bit-identical output in every combination. */
 #define NSC_GAT_CORESIDENT 1u
 #define NSC_GAT_SHARED_B 2u
+#define NSC_GAT_LDS_TILED 4u
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream);
 

@@ -412,6 +412,239 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 3: the stand-alone GEMM (one launch owns the chip).  What the round-2 ablations showed about gemm_nt_kernel:
+// its skeleton without a single MFMA (register-ring loads, ds_write_b128 staging at 79 B/clk/CU, a barrier per chunk)
+// takes 23 of input_proj's 35 us, the matrix pipe needs 12, and the two ADD UP: 2.2 workgroups per CU in lock step, wave
+// quantisation on top (568 tiles cost what 768 do).  This kernel changes the decomposition, the staging and who does what:
+//   * ONE round of workgroups where the shape allows it: the tile is (16 ACC) x 64 with ACC picked on the host
+//     (glds_pick_acc) so that the grid is at most one workgroup per CU (M = 4 541: ACC = 5 -> 228 tiles for input_proj,
+//     ACC = 6 -> 240 for lin; output_proj takes two rounds of ACC = 8).  A computing wave owns ACC accumulators (16 ACC rows
+//     x 16 columns): ACC independent MFMA chains, ACC + 1 operand reads per 4 ACC MFMAs, and 2 (1/(16 ACC) + 1/64) B of
+//     operand traffic per FLOP from L2 (0.056 at ACC = 5 against 0.094 for the 32 x 64 tiles of round 2).
+//   * staging by LDS-DMA (global_load_lds_dwordx4): no register ring, no ds_write pass.  A wave-instruction writes 1 KiB
+//     = 4 tile rows of one 64-deep chunk (256 B per row), lane-linear; bank conflicts are avoided by swizzling on the
+//     SOURCE side: the 16-byte slot s of tile row R holds the k-quad s ^ (R & 15), the operand read of lane (r, q) for
+//     k-block d takes slot (4 d + q) ^ r -- every 16-lane group of a ds_read_b128 hits 16 different slots.
+//   * three LDS stages, ONE raw s_barrier per chunk, counted vmcnt: chunk c + 2 is issued right after the barrier that
+//     retires chunk c, so one chunk stays in flight across every barrier (__syncthreads() would drain it).
+//   * wave specialisation (512 threads): waves 0-3 only compute (operand reads + MFMAs), waves 4-7 only stage (LDS-DMA issue
+//     + counted waits).  An LDS-DMA instruction costs the issuing wave 60-185 cycles of its in-order instruction stream
+//     (MI355X_MICROARCH.md, cycle constants): with the 9 of a chunk issued by the computing waves themselves the same kernel
+//     measured 24.7 us on input_proj at 4 541 rows, 22.8 us with them on waves of their own (round 2: 34.6).  The cyclic
+//     wave -> SIMD placement gives every SIMD one wave of each kind.
+// Every output element is still the chain chunk-ascending, d = 0..3, t = 0..3 of v_mfma_f32_16x16x4_f32 with operand
+// element t of lane (r, q) = k 64 c + 16 d + 4 q + t: bit-identical to the other GEMM kernels (tools/native/gemm_glds_probe.hip
+// compares every configuration with gemm_nt_kernel bit for bit).
+// ---------------------------------------------------------------------------------------------
+template <int N_> __device__ __forceinline__ void glds_wait_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_) : "memory");
+}
+
+template <int ACC, int EPI>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict__ A, int lda,
+                                                           const float *__restrict__ B, int ldb,
+                                                           const float *__restrict__ Bx, int M, int N,
+                                                           int n_main, int K, float *__restrict__ C, int ldc,
+                                                           GemmEpi ep)
+{
+    constexpr int BM = 16 * ACC, ROWS = BM + 64, NPW = ROWS / 16;   // NPW: LDS-DMA pieces (4 rows) per staging wave and chunk
+    constexpr int STAGE = ROWS * 64;                                // floats per stage
+    constexpr int LD = 68;                                          // epilogue staging stride
+    extern __shared__ __attribute__((aligned(1024))) float gemm_lds[];   // the ONLY LDS object of the kernel
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int m0 = (int)(tile / gridDim.x) * BM, n0 = (int)(tile % gridDim.x) * 64;
+    const int nchunks = (K + 63) >> 6;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[ACC];
+#pragma unroll
+    for (int h = 0; h < ACC; ++h) acc[h] = zero;
+    const bool active = n0 + wave * 16 < N;      // a computing wave whose columns all lie beyond N has nothing to do
+
+    if (wave8 >= 4) {
+        // ---- staging waves: piece j of a chunk = tile rows 4 (wave + 4 j) .. + 3, lane -> row + lane / 16, k-quad (lane % 16) ^ (row % 16)
+        const float *src[NPW];
+        const int kq_base = lane & 15;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int R = 4 * (wave + 4 * j) + (lane >> 4);
+            const int kq = kq_base ^ (R & 15);
+            const float *p;
+            if (4 * (wave + 4 * j) < BM) {                          // wave-uniform: a piece is all A or all B
+                const int gr = m0 + R;
+                p = A + (long long)(gr < M ? gr : M - 1) * lda;
+            } else {
+                int gc = n0 + R - BM;
+                gc = gc < N ? gc : N - 1;
+                p = (gc < n_main) ? B + (long long)gc * ldb : Bx + (long long)(gc - n_main) * ldb;
+            }
+            src[j] = p + 4 * kq;
+        }
+        auto issue = [&](int ch, int stage) {
+            const int kn = ch << 6;
+            float *dst0 = gemm_lds + stage * STAGE + wave * 256;
+            if (kn + 64 <= K) {                                     // workgroup-uniform
+#pragma unroll
+                for (int j = 0; j < NPW; ++j)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + kn),
+                                                     (__attribute__((address_space(3))) void *)(dst0 + j * 1024), 16, 0, 0);
+            } else {
+                // a short last chunk (K % 64 != 0): quads past K re-read quad 0 of the chunk (those k-blocks are skipped)
+#pragma unroll
+                for (int j = 0; j < NPW; ++j) {
+                    const int R = 4 * (wave + 4 * j) + (lane >> 4);
+                    const int kq = kq_base ^ (R & 15);
+                    const float *g = src[j] + kn - ((kn + 4 * kq + 4 <= K) ? 0 : 4 * kq);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)(dst0 + j * 1024), 16, 0, 0);
+                }
+            }
+        };
+        issue(0, 0);
+        if (1 < nchunks) issue(1, 1);
+        for (int c = 0; c < nchunks; ++c) {
+            // barrier c: this wave's pieces of chunk c have landed (at most the younger chunk's are outstanding), and every
+            // computing wave is done reading chunk c - 1, whose stage chunk c + 2 refills
+            if (c + 1 < nchunks) glds_wait_barrier<NPW>();
+            else glds_wait_barrier<0>();
+            if (c + 2 < nchunks) issue(c + 2, (c + 2) % 3);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // ---- computing waves
+        const int boff = (BM + 16 * wave + r) * 64, aoff = r * 64;
+        auto frags = [&](const float *st, int d, f32x4 &bv, f32x4 (&av)[ACC]) {
+            const int slot = 4 * ((4 * d + q) ^ r);
+            bv = *reinterpret_cast<const f32x4 *>(&st[boff + slot]);
+#pragma unroll
+            for (int h = 0; h < ACC; ++h) av[h] = *reinterpret_cast<const f32x4 *>(&st[aoff + h * 1024 + slot]);
+        };
+        auto mfmas = [&](const f32x4 &bv, const f32x4 (&av)[ACC], int t0, int t1) {
+#pragma unroll
+            for (int t = t0; t < t1; ++t)
+#pragma unroll
+                for (int h = 0; h < ACC; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+        };
+        glds_wait_barrier<0>();                                    // barrier 0 (this wave has nothing in flight)
+        f32x4 bv0, bv1, av0[ACC], av1[ACC];
+        if (active) frags(gemm_lds, 0, bv0, av0);
+        // One iteration = one 64-deep chunk = 16 ACC MFMAs.  The operand reads of k-block d + 1 go out between the two halves
+        // of the MFMAs of block d (the scheduler would sink every read to just before its first use -- seen in the ISA --
+        // hence the pinned order); the hand-over to the next chunk sits between the halves of the LAST block: by then this
+        // wave has read everything it needs from the stage (lgkmcnt(0)), after the barrier the next chunk's first operands
+        // are fetched and the second half of the MFMAs covers their latency.
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const float *st = gemm_lds + (ch % 3) * STAGE;
+            const float *nx = gemm_lds + ((ch + 1) % 3) * STAGE;
+            const int kleft = K - (ch << 6);
+            const bool last = ch + 1 == nchunks;
+            if (kleft >= 64) {
+                if (active) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(bv0, av0, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    frags(st, 1, bv1, av1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(bv0, av0, 2, 4);
+                    mfmas(bv1, av1, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    frags(st, 2, bv0, av0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(bv1, av1, 2, 4);
+                    mfmas(bv0, av0, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    frags(st, 3, bv1, av1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(bv0, av0, 2, 4);
+                    mfmas(bv1, av1, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!last) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // barrier ch + 1
+                    if (active) frags(nx, 0, bv0, av0);
+                }
+                if (active) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(bv1, av1, 2, 4);
+                }
+            } else {                                               // the short last chunk (K % 64 != 0)
+                if (active) {
+                    mfmas(bv0, av0, 0, 4);
+                    for (int d = 1; 16 * d < kleft; ++d) {
+                        frags(st, d, bv0, av0);
+                        mfmas(bv0, av0, 0, 4);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                               // nothing in flight, all reads done
+
+    // epilogue as in gemm_nt_kernel: the tile goes through LDS, rows leave as 256 contiguous bytes; all 8 waves store
+    float *Cs = gemm_lds;
+    if (wave8 < 4 && active) {
+#pragma unroll
+        for (int h = 0; h < ACC; ++h)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)                      // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+                Cs[(16 * h + 4 * q + reg) * LD + wave * 16 + r] = acc[h][reg];
+    }
+    __syncthreads();
+    const int c4t = tid & 15;
+    const int cg = n0 + 4 * c4t;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, bn_scale[4] = {1.f, 1.f, 1.f, 1.f}, bn_shift[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = (cg + j < N) ? cg + j : N - 1;
+        if (EPI != 0) bias[j] = ep.bias[col];
+        if (EPI == 1) {
+            const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
+            bn_scale[j] = invstd * ep.bn_w[col];
+            bn_shift[j] = ep.bn_b[col] - ep.bn_mean[col] * bn_scale[j];
+        }
+    }
+    const bool vec = (cg + 3 < n_main) && !(ldc & 3) && !(reinterpret_cast<unsigned long long>(C) & 15) &&
+                     (EPI != 2 || !ep.resid || (!(ep.ldr & 3) && !(reinterpret_cast<unsigned long long>(ep.resid) & 15)));
+#pragma unroll
+    for (int pass = 0; pass < (ACC + 1) / 2; ++pass) {
+        const int lr = pass * 32 + (tid >> 4), row = m0 + lr;
+        if (lr >= BM || row >= M) continue;
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(&Cs[lr * LD + 4 * c4t]);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        f32x4 rs = zero;
+        if (EPI == 2 && ep.resid && vec) rs = *reinterpret_cast<const f32x4 *>(ep.resid + (long long)row * ep.ldr + cg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (EPI != 0) v[j] = v[j] + bias[j];
+            if (EPI == 1) v[j] = fmaxf(v[j] * bn_scale[j] + bn_shift[j], 0.0f);
+        }
+        if (vec) {
+            if (EPI == 2 && ep.resid) { v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w; }
+            *reinterpret_cast<f32x4 *>(C + (long long)row * ldc + cg) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cg + j;
+                if (col >= N) continue;
+                if (col < n_main) {
+                    float o = v[j];
+                    if (EPI == 2 && ep.resid) o = o + ep.resid[(long long)row * ep.ldr + col];
+                    C[(long long)row * ldc + col] = o;
+                } else {
+                    float *aux = (col == n_main) ? ep.aux0 : ep.aux1;
+                    aux[row] = v[j];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-free variant of the same GEMM (NSC_GAT_CORESIDENT): operands are loaded from global memory into a
 // register ring of P k-blocks and moved to the MFMA layout by ds_bpermute (the LDS crossbar, no LDS
 // allocation); the four waves of a workgroup re-read the A rows through L1.  0 bytes of LDS and < 64 VGPRs,
@@ -878,6 +1111,68 @@ int gat_tune_env(const char *name, int def)
 }
 #endif
 
+// One configuration of gemm_glds_kernel.  Above 64 KB of dynamic LDS a kernel has to be opted in, and the attribute is
+// per DEVICE: one atomic per (instantiation, device) -- 0 not tried, 1 opted in, 2 refused.  Returns false when the
+// configuration cannot run here (the caller then takes gemm_nt_kernel: same results, bit for bit).
+template <int ACC, int EPI>
+bool launch_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, int ldb, const float *Bx, int M, int N,
+                     int n_main, int K, float *C, int ldc, const GemmEpi &ep)
+{
+    constexpr unsigned lds = 3 * (16 * ACC + 64) * 256;
+    static_assert(lds <= 160 * 1024, "LDS of a CU");
+    if (lds > 64 * 1024) {
+        static std::atomic<int> opted[16];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+        int s = opted[dev].load(std::memory_order_acquire);
+        if (s == 0) {
+            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<ACC, EPI>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 2;
+            opted[dev].store(s, std::memory_order_release);
+        }
+        if (s != 1) return false;
+    }
+    const dim3 grid((N + 63) / 64, (M + 16 * ACC - 1) / (16 * ACC));
+    hipLaunchKernelGGL((gemm_glds_kernel<ACC, EPI>), grid, dim3(512), lds, st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc,
+                       ep);
+    return true;
+}
+
+// Rows per tile (16 ACC) of the stand-alone GEMM: the grid should be ONE round of at most a workgroup per CU (256), and
+// among such grids the one with the least work per workgroup; when even 128-row tiles need several rounds, the cost is
+// rounds x (MFMA time of a tile + what a round costs besides: first operand round trip, epilogue, ramp).
+inline int glds_pick_acc(int M, int N, int K)
+{
+    const long long ncb = (N + 63) / 64, nch = (K + 63) / 64;
+    int best = 1;
+    long long best_cost = -1;
+    for (int a = 1; a <= 8; ++a) {
+        const long long tiles = ncb * ((M + 16 * a - 1) / (16 * a));
+        const long long rounds = (tiles + 255) / 256;
+        const long long cost = rounds * (a * nch * 512 + 3000);    // cycles: 16 MFMAs of 32 per chunk and accumulator
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = a; }
+    }
+    return best;
+}
+
+template <int EPI>
+bool launch_glds(hipStream_t st, const float *A, int lda, const float *B, int ldb, const float *Bx, int M, int N,
+                 int n_main, int K, float *C, int ldc, const GemmEpi &ep)
+{
+    // LDS-DMA moves 16 bytes per lane: rows must be 16-byte aligned at every k-quad
+    if ((lda & 3) || (ldb & 3) || (reinterpret_cast<unsigned long long>(A) & 15) ||
+        (reinterpret_cast<unsigned long long>(B) & 15) || (Bx && (reinterpret_cast<unsigned long long>(Bx) & 15)) || (K & 15))
+        return false;
+#define NSC_GLDS_CASE(a)                                                                                              \
+    case a: return launch_glds_cfg<a, EPI>(st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep);
+    switch (glds_pick_acc(M, N, K)) {
+        NSC_GLDS_CASE(1) NSC_GLDS_CASE(2) NSC_GLDS_CASE(3) NSC_GLDS_CASE(4)
+        NSC_GLDS_CASE(5) NSC_GLDS_CASE(6) NSC_GLDS_CASE(7) NSC_GLDS_CASE(8)
+    }
+#undef NSC_GLDS_CASE
+    return false;
+}
+
 template <int EPI>
 void launch_gemm(hipStream_t st, int cores, const float *A, int lda, const float *B, int ldb, const float *Bx,
                  int M, int N, int n_main, int K, float *C, int ldc, const GemmEpi &ep)
@@ -885,7 +1180,9 @@ void launch_gemm(hipStream_t st, int cores, const float *A, int lda, const float
     // Tile choice (measured at M = 1 024 and 4 541, round 2): 32-row tiles (two accumulators share the B operand, 1.7x
     // less operand traffic per MFMA) as soon as they still give >= 1.5 workgroups per CU; below that 16-row tiles, so
     // that every SIMD of the chip gets a wave -- these GEMMs are operand-latency-, not MFMA-bound.
-    const bool coresident = cores != 0;
+    // cores: 0 stand-alone (gemm_glds_kernel where it can run), 1 / 2 the co-resident sets, 3 the round-2 LDS-tiled kernels
+    if (cores == 0 && launch_glds<EPI>(st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep)) return;
+    const bool coresident = cores == 1 || cores == 2;
     if (cores == 2) {                              // small-LDS co-resident form: 64 x 64 tiles, B shared through 10 KB of LDS
         const dim3 gs((N + 63) / 64, (M + 63) / 64);
         hipLaunchKernelGGL((gemm_nt_share_kernel<EPI>), gs, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep);
@@ -1032,9 +1329,10 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream_)
 {
-    if (flags & ~(uint32_t)(NSC_GAT_CORESIDENT | NSC_GAT_SHARED_B)) return NSC_EINVAL;
+    if (flags & ~(uint32_t)(NSC_GAT_CORESIDENT | NSC_GAT_SHARED_B | NSC_GAT_LDS_TILED)) return NSC_EINVAL;
     if ((flags & NSC_GAT_SHARED_B) && !(flags & NSC_GAT_CORESIDENT)) return NSC_EINVAL;
-    const int cores = (flags & NSC_GAT_CORESIDENT) ? ((flags & NSC_GAT_SHARED_B) ? 2 : 1) : 0;
+    if ((flags & NSC_GAT_LDS_TILED) && (flags & NSC_GAT_CORESIDENT)) return NSC_EINVAL;
+    const int cores = (flags & NSC_GAT_CORESIDENT) ? ((flags & NSC_GAT_SHARED_B) ? 2 : 1) : (flags & NSC_GAT_LDS_TILED) ? 3 : 0;
     int stt = check_model(m);
     if (stt != NSC_OK) return stt;
     if (!g || g->n_nodes < 0) return NSC_EINVAL;

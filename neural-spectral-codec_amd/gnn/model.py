@@ -196,7 +196,8 @@ class SpectralGNN(nn.Module):
         self._struct_cache = None          # (key, GatModel, folded tensor)
         # True: launch the LDS-free, low-VGPR kernel set (NSC_GAT_CORESIDENT) whose workgroups fit beside a
         # resident encoder grid -- used by distributed.ShardedDescriptorPath(pipeline=True).  "shared_b": that set with
-        # the small-LDS GEMMs (NSC_GAT_SHARED_B).  Same output, bit for bit.
+        # the small-LDS GEMMs (NSC_GAT_SHARED_B).  "lds_tiled": the stand-alone forward with the round-2 GEMMs
+        # (NSC_GAT_LDS_TILED) instead of the LDS-DMA GEMM.  Same output, bit for bit.
         self.coresident = False
         self._seed_dev = None              # device int64[1]: dropout seed read by the kernels at run time (captured steps)
         self._direct_grads = False         # backward adds straight into the parameters' .grad tensors (GNNTrainer's steps)
@@ -352,7 +353,7 @@ class SpectralGNN(nn.Module):
         with torch.cuda.device(dev):
             st = L.nsc_gat_forward_ex(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
                                       _lib.ptr(out), _lib.ptr(alpha), _lib.ptr(ws), nbytes,
-                                      {False: 0, True: 1, "shared_b": 3}[getattr(self, "coresident", False)],
+                                      {False: 0, True: 1, "shared_b": 3, "lds_tiled": 4}[getattr(self, "coresident", False)],
                                       _lib.stream_ptr(dev))
         _lib.check(st, "nsc_gat_forward_ex")
         return out, alpha, csr

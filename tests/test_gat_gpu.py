@@ -132,9 +132,29 @@ def test_coresident_variant_is_bit_identical(n, edge_dim):
         b = m(g)
         m.gnn.coresident = "shared_b"                 # NSC_GAT_SHARED_B: 64 x 64 tiles, weight block shared through 10 KB of LDS
         c = m(g)
+        m.gnn.coresident = "lds_tiled"                # NSC_GAT_LDS_TILED: the round-2 register-staged GEMMs
+        d = m(g)
+        m.gnn.coresident = False
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    _check(b, m, g)
+
+
+@pytest.mark.parametrize("n", [15, 16, 17, 255, 256, 257, 1279, 1280, 1281, 2047, 2049, 4095, 4097, 6000, 9000])
+def test_glds_gemm_tile_boundaries(n):
+    """The default GEMM (gemm_glds_kernel) picks its tile height 16 ACC from the node count (one round of workgroups where
+    that is possible): sizes either side of the switches between ACC values, ragged last tiles, several rounds -- every
+    kernel set bit-identical, within the oracle bar."""
+    m = _model()
+    g = gm.synthetic_chain_graph(n, device="cuda", seed=n)
+    with torch.no_grad():
+        a = m(g)
+        m.gnn.coresident = True
+        b = m(g)
+        m.gnn.coresident = "lds_tiled"
+        c = m(g)
         m.gnn.coresident = False
     assert torch.equal(a, b) and torch.equal(a, c)
-    _check(b, m, g)
+    _check(a, m, g)
 
 
 @pytest.mark.parametrize("n", [2496, 2497, 2561, 3071])

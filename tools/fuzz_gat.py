@@ -55,12 +55,14 @@ for gi in range(n_graphs):
         b = m(g)
         m.gnn.coresident = "shared_b"
         c = m(g)
+        m.gnn.coresident = "lds_tiled"
+        d = m(g)
         m.gnn.coresident = False
-    assert torch.equal(a, b) and torch.equal(a, c), f"graph {gi}: kernel sets differ"
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d), f"graph {gi}: kernel sets differ"
     ref = go.forward_reference(m, g)
     err = ((a.cpu() - ref).abs().max() / ref.abs().max()).item()
     worst = max(worst, err)
     assert err < 1e-4, f"graph {gi} (kind {kind}, n {n}, E {ei.shape[1]}): rel err {err}"
     if gi % 20 == 19:
         print(f"{gi + 1} graphs, worst rel err {worst:.2e} ({time.time() - t0:.0f} s)", flush=True)
-print(f"TOTAL {n_graphs} graphs: all three kernel sets bit-identical, worst relative error vs restatement {worst:.2e}")
+print(f"TOTAL {n_graphs} graphs: all four kernel sets bit-identical, worst relative error vs restatement {worst:.2e}")

@@ -1,0 +1,133 @@
+// Stand-alone A/B of the GEMM kernels of csrc/nsc_gat.hip on the three shapes of the GNN forward (input_proj 800 -> 256,
+// lin 256 -> 256 + 2 attention columns, output_proj 256 -> 800) at M rows:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I include -o /tmp/gemm_glds_probe tools/native/gemm_glds_probe.hip
+//   /tmp/gemm_glds_probe [M=4541] [reps=200]
+// For every shape: the shipped dispatcher's choice of gemm_nt_kernel (reference result), then every ACC configuration
+// of gemm_glds_kernel -- output compared with the reference BIT FOR BIT (main columns and the two aux columns), time per launch
+// from HIP events over `reps` back-to-back launches.  Exit status 1 when any configuration differs.
+#include "../../neural-spectral-codec_amd/csrc/nsc_gat.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+static float *dalloc(size_t n, unsigned seed, float scale)
+{
+    std::vector<float> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        h[i] = ((float)(s >> 8) / 16777216.0f - 0.5f) * scale;
+    }
+    float *d = nullptr;
+    if (hipMalloc(&d, n * sizeof(float)) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); exit(2); }
+    hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice);
+    return d;
+}
+
+struct Shape { const char *name; int N, n_main, K, epi; };
+
+static int g_bad = 0;
+
+template <typename F>
+static float time_us(F launch, int reps)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms * 1000.0f / reps;
+}
+
+template <int ACC, int EPI>
+static void one_cfg(const Shape &s, int M, int reps, const float *A, const float *B, const float *Bx, float *C, float *aux0,
+                    float *aux1, const GemmEpi &ep0, const std::vector<float> &ref, const std::vector<float> &ra0,
+                    const std::vector<float> &ra1)
+{
+    GemmEpi ep = ep0;
+    const size_t nc = (size_t)M * s.n_main;
+    hipMemset(C, 0xff, nc * sizeof(float));
+    hipMemset(aux0, 0xff, M * sizeof(float));
+    hipMemset(aux1, 0xff, M * sizeof(float));
+    if (!launch_glds_cfg<ACC, EPI>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep)) {
+        printf("  glds ACC=%d: not launchable\n", ACC);
+        return;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { printf("  glds ACC=%d: launch failed\n", ACC); g_bad = 1; return; }
+    std::vector<float> out(nc), a0(M), a1(M);
+    hipMemcpy(out.data(), C, nc * sizeof(float), hipMemcpyDeviceToHost);
+    size_t diff = 0;
+    for (size_t i = 0; i < nc; ++i) diff += memcmp(&out[i], &ref[i], 4) != 0;
+    if (s.N > s.n_main) {
+        hipMemcpy(a0.data(), aux0, M * sizeof(float), hipMemcpyDeviceToHost);
+        hipMemcpy(a1.data(), aux1, M * sizeof(float), hipMemcpyDeviceToHost);
+        for (int i = 0; i < M; ++i) diff += (memcmp(&a0[i], &ra0[i], 4) != 0) + (memcmp(&a1[i], &ra1[i], 4) != 0);
+    }
+    const float us = time_us([&] { launch_glds_cfg<ACC, EPI>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep); }, reps);
+    const long long tiles = (long long)((s.N + 63) / 64) * ((M + 16 * ACC - 1) / (16 * ACC));
+    const double tf = 2.0 * M * s.n_main * s.K / us / 1e6;
+    printf("  glds ACC=%d tiles=%4lld lds=%6d B: %7.2f us  %6.1f TF/s (%4.1f %%)  differing elements %zu%s\n", ACC, tiles,
+           3 * (16 * ACC + 64) * 256, us, tf, tf / 157.3 * 100, diff, diff ? "   <-- MISMATCH" : "");
+    if (diff) g_bad = 1;
+    fflush(stdout);
+}
+
+template <int EPI>
+static void shape(const Shape &s, int M, int reps, int pick_only)
+{
+    float *A = dalloc((size_t)M * s.K, 1 + s.epi, 2.0f), *B = dalloc((size_t)s.n_main * s.K, 7 + s.epi, 0.25f);
+    float *Bx = dalloc((size_t)2 * s.K, 11, 0.25f), *R = dalloc((size_t)M * s.n_main, 13, 1.0f);
+    float *bias = dalloc(s.n_main, 17, 1.0f), *bw = dalloc(s.n_main, 19, 1.0f), *bb = dalloc(s.n_main, 23, 1.0f);
+    float *bm = dalloc(s.n_main, 29, 1.0f), *bv = dalloc(s.n_main, 31, 1.0f);
+    {   // variances must be positive
+        std::vector<float> h(s.n_main);
+        hipMemcpy(h.data(), bv, s.n_main * 4, hipMemcpyDeviceToHost);
+        for (auto &x : h) x = 0.5f + fabsf(x);
+        hipMemcpy(bv, h.data(), s.n_main * 4, hipMemcpyHostToDevice);
+    }
+    float *C = nullptr, *aux0 = nullptr, *aux1 = nullptr;
+    hipMalloc(&C, (size_t)M * s.n_main * 4); hipMalloc(&aux0, M * 4); hipMalloc(&aux1, M * 4);
+    GemmEpi ep = {};
+    ep.bias = bias; ep.bn_w = bw; ep.bn_b = bb; ep.bn_mean = bm; ep.bn_var = bv; ep.bn_eps = 1e-5f; ep.relu = 1;
+    if (EPI == 2) { ep.resid = R; ep.ldr = s.n_main; }
+    ep.aux0 = aux0; ep.aux1 = aux1;
+
+    printf("%s: M=%d N=%d (+%d aux) K=%d  %.3f GFLOP\n", s.name, M, s.n_main, s.N - s.n_main, s.K, 2.0 * M * s.n_main * s.K / 1e9);
+    // reference: gemm_nt_kernel through the round-2 dispatcher (cores = 3: never the glds path)
+    launch_gemm<EPI>(0, 3, A, s.K, B, s.K, s.N > s.n_main ? Bx : nullptr, M, s.N, s.n_main, s.K, C, s.n_main, ep);
+    hipDeviceSynchronize();
+    const size_t nc = (size_t)M * s.n_main;
+    std::vector<float> ref(nc), ra0(M), ra1(M);
+    hipMemcpy(ref.data(), C, nc * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(ra0.data(), aux0, M * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(ra1.data(), aux1, M * 4, hipMemcpyDeviceToHost);
+    const float us = time_us([&] { launch_gemm<EPI>(0, 3, A, s.K, B, s.K, s.N > s.n_main ? Bx : nullptr, M, s.N, s.n_main, s.K, C, s.n_main, ep); }, reps);
+    const double tf = 2.0 * M * s.n_main * s.K / us / 1e6;
+    printf("  gemm_nt_kernel (round 2):            %7.2f us  %6.1f TF/s (%4.1f %%)\n", us, tf, tf / 157.3 * 100);
+    const float *bx = s.N > s.n_main ? Bx : nullptr;
+    const int pick = glds_pick_acc(M, s.N, s.K);
+    printf("  glds_pick_acc -> %d\n", pick);
+#define CFG(a) if (!pick_only || pick == a) one_cfg<a, EPI>(s, M, reps, A, B, bx, C, aux0, aux1, ep, ref, ra0, ra1);
+    CFG(1) CFG(2) CFG(3) CFG(4) CFG(5) CFG(6) CFG(7) CFG(8)
+#undef CFG
+    hipFree(A); hipFree(B); hipFree(Bx); hipFree(R); hipFree(bias); hipFree(bw); hipFree(bb); hipFree(bm); hipFree(bv);
+    hipFree(C); hipFree(aux0); hipFree(aux1);
+}
+
+int main(int argc, char **argv)
+{
+    const int M = argc > 1 ? atoi(argv[1]) : 4541, reps = argc > 2 ? atoi(argv[2]) : 200;
+    const int pick_only = argc > 3 ? atoi(argv[3]) : 0;
+    const Shape in = {"input_proj", 256, 256, 800, 1}, lin = {"lin", 258, 256, 256, 0}, outp = {"output_proj", 800, 800, 256, 2};
+    shape<1>(in, M, reps, pick_only);
+    shape<0>(lin, M, reps, pick_only);
+    shape<2>(outp, M, reps, pick_only);
+    return g_bad;
+}

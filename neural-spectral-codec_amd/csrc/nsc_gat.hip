@@ -441,7 +441,7 @@ template <int N_> __device__ __forceinline__ void glds_wait_barrier()
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
-template <int ACC, int EPI>
+template <int ACC, int EPI, int NST = 3>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict__ A, int lda,
                                                            const float *__restrict__ B, int ldb,
                                                            const float *__restrict__ Bx, int M, int N,
@@ -465,6 +465,23 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
 #pragma unroll
     for (int h = 0; h < ACC; ++h) acc[h] = zero;
     const bool active = n0 + wave * 16 < N;      // a computing wave whose columns all lie beyond N has nothing to do
+
+    // epilogue operands: the bias loads of the computing waves go out at once and stay in flight across the main loop (their
+    // barriers do not wait for vector memory); the staging waves fetch theirs after the last chunk.  The 20 BatchNorm loads
+    // of EPI 1 stay behind the second epilogue barrier in every wave (ahead of the loop, or ahead of the barriers, they
+    // measured +0.8 us on input_proj)
+    const int c4t = tid & 15;
+    const int cg = n0 + 4 * c4t;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, raw_var[4] = {1.f, 1.f, 1.f, 1.f}, raw_w[4] = {1.f, 1.f, 1.f, 1.f};
+    float raw_b[4] = {0.f, 0.f, 0.f, 0.f}, raw_mean[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_epilogue = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = (cg + j < N) ? cg + j : N - 1;
+            if (EPI != 0) bias[j] = ep.bias[col];
+            if (EPI == 1) { raw_var[j] = ep.bn_var[col]; raw_w[j] = ep.bn_w[col]; raw_b[j] = ep.bn_b[col]; raw_mean[j] = ep.bn_mean[col]; }
+        }
+    };
 
     if (wave8 >= 4) {
         // ---- staging waves: piece j of a chunk = tile rows 4 (wave + 4 j) .. + 3, lane -> row + lane / 16, k-quad (lane % 16) ^ (row % 16)
@@ -506,15 +523,21 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
             }
         };
         issue(0, 0);
-        if (1 < nchunks) issue(1, 1);
+        if (NST == 3 && 1 < nchunks) issue(1, 1);
+        // (not ahead of the loop: with ordinary loads pending beside LDS-DMA hipcc drains the queue inside the loop -- measured
+        // +1 us on input_proj; the staging waves have nothing else to do after their last chunk anyway)
         for (int c = 0; c < nchunks; ++c) {
-            // barrier c: this wave's pieces of chunk c have landed (at most the younger chunk's are outstanding), and every
-            // computing wave is done reading chunk c - 1, whose stage chunk c + 2 refills
-            if (c + 1 < nchunks) glds_wait_barrier<NPW>();
+            // barrier c: this wave's pieces of chunk c have landed (with three stages at most the younger chunk's are
+            // outstanding), and every computing wave is done reading chunk c - 1, whose stage the next issue refills
+            if (NST == 3 && c + 1 < nchunks) glds_wait_barrier<NPW>();
             else glds_wait_barrier<0>();
-            if (c + 2 < nchunks) issue(c + 2, (c + 2) % 3);
+#if defined(NSC_GLDS_ABL) && (NSC_GLDS_ABL & 2)                               // ablation build: no refills after the prologue
+            continue;
+#endif
+            if (c + NST - 1 < nchunks) issue(c + NST - 1, (c + NST - 1) % NST);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (EPI != 1) load_epilogue();
     } else {
         // ---- computing waves
         const int boff = (BM + 16 * wave + r) * 64, aoff = r * 64;
@@ -528,9 +551,16 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
 #pragma unroll
             for (int t = t0; t < t1; ++t)
 #pragma unroll
-                for (int h = 0; h < ACC; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+                for (int h = 0; h < ACC; ++h) {
+#if defined(NSC_GLDS_ABL) && (NSC_GLDS_ABL & 1)                                       // ablation build: no MFMAs, operands kept alive
+                    acc[h][t] += av[h][t] * bv[t];
+                    continue;
+#endif
+                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+                }
         };
-        glds_wait_barrier<0>();                                    // barrier 0 (this wave has nothing in flight)
+        if (EPI != 1) load_epilogue();
+        asm volatile("s_barrier" ::: "memory");                    // barrier 0 (no LDS-DMA of this wave's to wait for)
         f32x4 bv0, bv1, av0[ACC], av1[ACC];
         if (active) frags(gemm_lds, 0, bv0, av0);
         // One iteration = one 64-deep chunk = 16 ACC MFMAs.  The operand reads of k-block d + 1 go out between the two halves
@@ -539,8 +569,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
         // wave has read everything it needs from the stage (lgkmcnt(0)), after the barrier the next chunk's first operands
         // are fetched and the second half of the MFMAs covers their latency.
         for (int ch = 0; ch < nchunks; ++ch) {
-            const float *st = gemm_lds + (ch % 3) * STAGE;
-            const float *nx = gemm_lds + ((ch + 1) % 3) * STAGE;
+            const float *st = gemm_lds + (ch % NST) * STAGE;
+            const float *nx = gemm_lds + ((ch + 1) % NST) * STAGE;
             const int kleft = K - (ch << 6);
             const bool last = ch + 1 == nchunks;
             if (kleft >= 64) {
@@ -595,17 +625,14 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
                 Cs[(16 * h + 4 * q + reg) * LD + wave * 16 + r] = acc[h][reg];
     }
     __syncthreads();
-    const int c4t = tid & 15;
-    const int cg = n0 + 4 * c4t;
-    float bias[4] = {0.f, 0.f, 0.f, 0.f}, bn_scale[4] = {1.f, 1.f, 1.f, 1.f}, bn_shift[4] = {0.f, 0.f, 0.f, 0.f};
+    float bn_scale[4] = {1.f, 1.f, 1.f, 1.f}, bn_shift[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == 1) {
+        load_epilogue();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = (cg + j < N) ? cg + j : N - 1;
-        if (EPI != 0) bias[j] = ep.bias[col];
-        if (EPI == 1) {
-            const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
-            bn_scale[j] = invstd * ep.bn_w[col];
-            bn_shift[j] = ep.bn_b[col] - ep.bn_mean[col] * bn_scale[j];
+        for (int j = 0; j < 4; ++j) {                              // torch batch_norm eval: alpha = invstd * weight, beta = bias - mean * alpha
+            const float invstd = 1.0f / sqrtf(raw_var[j] + ep.bn_eps);
+            bn_scale[j] = invstd * raw_w[j];
+            bn_shift[j] = raw_b[j] - raw_mean[j] * bn_scale[j];
         }
     }
     const bool vec = (cg + 3 < n_main) && !(ldc & 3) && !(reinterpret_cast<unsigned long long>(C) & 15) &&
@@ -1114,11 +1141,11 @@ int gat_tune_env(const char *name, int def)
 // One configuration of gemm_glds_kernel.  Above 64 KB of dynamic LDS a kernel has to be opted in, and the attribute is
 // per DEVICE: one atomic per (instantiation, device) -- 0 not tried, 1 opted in, 2 refused.  Returns false when the
 // configuration cannot run here (the caller then takes gemm_nt_kernel: same results, bit for bit).
-template <int ACC, int EPI>
+template <int ACC, int EPI, int NST = 3>
 bool launch_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, int ldb, const float *Bx, int M, int N,
                      int n_main, int K, float *C, int ldc, const GemmEpi &ep)
 {
-    constexpr unsigned lds = 3 * (16 * ACC + 64) * 256;
+    constexpr unsigned lds = NST * (16 * ACC + 64) * 256;
     static_assert(lds <= 160 * 1024, "LDS of a CU");
     if (lds > 64 * 1024) {
         static std::atomic<int> opted[16];
@@ -1126,14 +1153,14 @@ bool launch_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, in
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
         int s = opted[dev].load(std::memory_order_acquire);
         if (s == 0) {
-            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<ACC, EPI>),
+            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<ACC, EPI, NST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 2;
             opted[dev].store(s, std::memory_order_release);
         }
         if (s != 1) return false;
     }
     const dim3 grid((N + 63) / 64, (M + 16 * ACC - 1) / (16 * ACC));
-    hipLaunchKernelGGL((gemm_glds_kernel<ACC, EPI>), grid, dim3(512), lds, st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc,
+    hipLaunchKernelGGL((gemm_glds_kernel<ACC, EPI, NST>), grid, dim3(512), lds, st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc,
                        ep);
     return true;
 }

@@ -177,9 +177,20 @@ __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part
                                                  double *sa, double *sb, const ColFinal &f)
 {
     // 64 columns per workgroup, the R partial rows split over the 4 waves (fixed order -> deterministic)
+    // (loads in groups of 8 ahead of the adds: one partial per L2 round trip was a 5 us latency chain; the order of the
+    // additions is unchanged)
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = ry; r < R; r += 4) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
+    if (c < C) {
+        int r = ry;
+        for (; r + 28 < R; r += 32) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(&part[((long long)(r + 4 * u) * C + c) * 2]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
+        }
+        for (; r < R; r += 4) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
+    }
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();
     if (ry != 0 || c >= C) return;
@@ -219,15 +230,28 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__r
     double a = 0.0, b = 0.0;
     if (c < C) {
         const float m = qm ? qm[c] : 0.0f, s = qs ? qs[c] : 1.0f;
-        for (int n = n0 + ry; n < n1; n += 4) {
-            const float p = P[(long long)n * C + c];
-            a += (double)(w ? p * w[n] : p);
+        auto step = [&](float p, float wv, float qv) {
+            a += (double)(w ? p * wv : p);
             if (Q) {
-                float qv = Q[(long long)n * C + c];
                 if (qm) qv = (qv - m) * s;
                 b += (double)p * (double)qv;
             }
+        };
+        // 8 rows' loads go out before the first add (one row per round trip was an 8 us latency chain for 16 rows per
+        // thread); the additions keep their order
+        int n = n0 + ry;
+        for (; n + 28 < n1; n += 32) {
+            float pv[8], wv[8], qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                pv[u] = P[(long long)(n + 4 * u) * C + c];
+                wv[u] = w ? w[n + 4 * u] : 1.0f;
+                qv[u] = Q ? Q[(long long)(n + 4 * u) * C + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(pv[u], wv[u], qv[u]);
         }
+        for (; n < n1; n += 4) step(P[(long long)n * C + c], w ? w[n] : 1.0f, Q ? Q[(long long)n * C + c] : 0.0f);
     }
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();

@@ -27,7 +27,10 @@ static float *dalloc(size_t n, unsigned seed, float scale)
 
 struct Shape { const char *name; int N, n_main, K, epi; };
 
-static int g_bad = 0;
+#ifndef NSC_GLDS_ABL
+#define NSC_GLDS_ABL 0            // ablation builds (-DNSC_GLDS_ABL=1 no MFMAs, 2 no refills, 3 both): timings only
+#endif
+static int g_bad = 0, g_abl = NSC_GLDS_ABL;
 
 template <typename F>
 static float time_us(F launch, int reps)
@@ -46,7 +49,7 @@ static float time_us(F launch, int reps)
     return ms * 1000.0f / reps;
 }
 
-template <int ACC, int EPI>
+template <int ACC, int EPI, int NST>
 static void one_cfg(const Shape &s, int M, int reps, const float *A, const float *B, const float *Bx, float *C, float *aux0,
                     float *aux1, const GemmEpi &ep0, const std::vector<float> &ref, const std::vector<float> &ra0,
                     const std::vector<float> &ra1)
@@ -56,7 +59,7 @@ static void one_cfg(const Shape &s, int M, int reps, const float *A, const float
     hipMemset(C, 0xff, nc * sizeof(float));
     hipMemset(aux0, 0xff, M * sizeof(float));
     hipMemset(aux1, 0xff, M * sizeof(float));
-    if (!launch_glds_cfg<ACC, EPI>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep)) {
+    if (!launch_glds_cfg<ACC, EPI, NST>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep)) {
         printf("  glds ACC=%d: not launchable\n", ACC);
         return;
     }
@@ -70,12 +73,12 @@ static void one_cfg(const Shape &s, int M, int reps, const float *A, const float
         hipMemcpy(a1.data(), aux1, M * sizeof(float), hipMemcpyDeviceToHost);
         for (int i = 0; i < M; ++i) diff += (memcmp(&a0[i], &ra0[i], 4) != 0) + (memcmp(&a1[i], &ra1[i], 4) != 0);
     }
-    const float us = time_us([&] { launch_glds_cfg<ACC, EPI>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep); }, reps);
+    const float us = time_us([&] { launch_glds_cfg<ACC, EPI, NST>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep); }, reps);
     const long long tiles = (long long)((s.N + 63) / 64) * ((M + 16 * ACC - 1) / (16 * ACC));
     const double tf = 2.0 * M * s.n_main * s.K / us / 1e6;
-    printf("  glds ACC=%d tiles=%4lld lds=%6d B: %7.2f us  %6.1f TF/s (%4.1f %%)  differing elements %zu%s\n", ACC, tiles,
-           3 * (16 * ACC + 64) * 256, us, tf, tf / 157.3 * 100, diff, diff ? "   <-- MISMATCH" : "");
-    if (diff) g_bad = 1;
+    printf("  glds ACC=%d NST=%d tiles=%4lld lds=%6d B: %7.2f us  %6.1f TF/s (%4.1f %%)  differing elements %zu%s\n", ACC, NST, tiles,
+           NST * (16 * ACC + 64) * 256, us, tf, tf / 157.3 * 100, diff, diff ? "   <-- MISMATCH" : "");
+    if (diff && !g_abl) g_bad = 1;
     fflush(stdout);
 }
 
@@ -114,8 +117,9 @@ static void shape(const Shape &s, int M, int reps, int pick_only)
     const float *bx = s.N > s.n_main ? Bx : nullptr;
     const int pick = glds_pick_acc(M, s.N, s.K);
     printf("  glds_pick_acc -> %d\n", pick);
-#define CFG(a) if (!pick_only || pick == a) one_cfg<a, EPI>(s, M, reps, A, B, bx, C, aux0, aux1, ep, ref, ra0, ra1);
-    CFG(1) CFG(2) CFG(3) CFG(4) CFG(5) CFG(6) CFG(7) CFG(8)
+#define CFG(a, n) if (!pick_only || pick == a) one_cfg<a, EPI, n>(s, M, reps, A, B, bx, C, aux0, aux1, ep, ref, ra0, ra1);
+    CFG(1, 3) CFG(2, 3) CFG(3, 3) CFG(4, 3) CFG(5, 3) CFG(6, 3) CFG(7, 3) CFG(8, 3)
+    CFG(1, 2) CFG(2, 2) CFG(3, 2) CFG(4, 2) CFG(5, 2) CFG(6, 2) CFG(7, 2) CFG(8, 2)
 #undef CFG
     hipFree(A); hipFree(B); hipFree(Bx); hipFree(R); hipFree(bias); hipFree(bw); hipFree(bb); hipFree(bm); hipFree(bv);
     hipFree(C); hipFree(aux0); hipFree(aux1);

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 static float *dalloc(size_t n, unsigned seed, float scale)
 {
@@ -49,7 +50,7 @@ static float time_us(F launch, int reps)
     return ms * 1000.0f / reps;
 }
 
-template <int ACC, int EPI, int NST>
+template <int ACC, int EPI, int NST, int BC>
 static void one_cfg(const Shape &s, int M, int reps, const float *A, const float *B, const float *Bx, float *C, float *aux0,
                     float *aux1, const GemmEpi &ep0, const std::vector<float> &ref, const std::vector<float> &ra0,
                     const std::vector<float> &ra1)
@@ -59,7 +60,7 @@ static void one_cfg(const Shape &s, int M, int reps, const float *A, const float
     hipMemset(C, 0xff, nc * sizeof(float));
     hipMemset(aux0, 0xff, M * sizeof(float));
     hipMemset(aux1, 0xff, M * sizeof(float));
-    if (!launch_glds_cfg<ACC, EPI, NST>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep)) {
+    if (!launch_glds_cfg<ACC, EPI, NST, BC>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep)) {
         printf("  glds ACC=%d: not launchable\n", ACC);
         return;
     }
@@ -73,12 +74,24 @@ static void one_cfg(const Shape &s, int M, int reps, const float *A, const float
         hipMemcpy(a1.data(), aux1, M * sizeof(float), hipMemcpyDeviceToHost);
         for (int i = 0; i < M; ++i) diff += (memcmp(&a0[i], &ra0[i], 4) != 0) + (memcmp(&a1[i], &ra1[i], 4) != 0);
     }
-    const float us = time_us([&] { launch_glds_cfg<ACC, EPI, NST>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep); }, reps);
-    const long long tiles = (long long)((s.N + 63) / 64) * ((M + 16 * ACC - 1) / (16 * ACC));
+    const float us = time_us([&] { launch_glds_cfg<ACC, EPI, NST, BC>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep); }, reps);
+    const long long tiles = (long long)((s.N + 64 * BC - 1) / (64 * BC)) * ((M + 16 * ACC - 1) / (16 * ACC));
     const double tf = 2.0 * M * s.n_main * s.K / us / 1e6;
-    printf("  glds ACC=%d NST=%d tiles=%4lld lds=%6d B: %7.2f us  %6.1f TF/s (%4.1f %%)  differing elements %zu%s\n", ACC, NST, tiles,
-           NST * (16 * ACC + 64) * 256, us, tf, tf / 157.3 * 100, diff, diff ? "   <-- MISMATCH" : "");
+    printf("  glds ACC=%d BC=%d NST=%d tiles=%4lld lds=%6d B: %7.2f us  %6.1f TF/s (%4.1f %%)  differing elements %zu%s\n", ACC, BC, NST, tiles,
+           NST * (16 * ACC + 64 * BC) * 256, us, tf, tf / 157.3 * 100, diff, diff ? "   <-- MISMATCH" : "");
     if (diff && !g_abl) g_bad = 1;
+#ifdef NSC_GLDS_CLOCK                // diagnostic build: in-kernel clock of the main loop (median over the workgroups of the last launch)
+    if (EPI != 0) {
+        std::vector<int> cyc(tiles), tick(tiles);
+        hipMemcpy(cyc.data(), aux0, tiles * sizeof(int), hipMemcpyDeviceToHost);
+        hipMemcpy(tick.data(), aux1, tiles * sizeof(int), hipMemcpyDeviceToHost);
+        std::vector<double> ghz(tiles);
+        for (long long i = 0; i < tiles; ++i) ghz[i] = tick[i] > 0 ? (double)cyc[i] / tick[i] * 0.1 : 0.0;
+        std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end()); std::sort(tick.begin(), tick.end());
+        printf("      main loop per workgroup: median %d shader cycles in %.2f us -> in-kernel clock %.2f GHz (min %.2f, max %.2f)\n",
+               cyc[tiles / 2], tick[tiles / 2] * 0.01, ghz[tiles / 2], ghz[0], ghz[tiles - 1]);
+    }
+#endif
     fflush(stdout);
 }
 
@@ -115,11 +128,11 @@ static void shape(const Shape &s, int M, int reps, int pick_only)
     const double tf = 2.0 * M * s.n_main * s.K / us / 1e6;
     printf("  gemm_nt_kernel (round 2):            %7.2f us  %6.1f TF/s (%4.1f %%)\n", us, tf, tf / 157.3 * 100);
     const float *bx = s.N > s.n_main ? Bx : nullptr;
-    const int pick = glds_pick_acc(M, s.N, s.K);
-    printf("  glds_pick_acc -> %d\n", pick);
-#define CFG(a, n) if (!pick_only || pick == a) one_cfg<a, EPI, n>(s, M, reps, A, B, bx, C, aux0, aux1, ep, ref, ra0, ra1);
-    CFG(1, 3) CFG(2, 3) CFG(3, 3) CFG(4, 3) CFG(5, 3) CFG(6, 3) CFG(7, 3) CFG(8, 3)
-    CFG(1, 2) CFG(2, 2) CFG(3, 2) CFG(4, 2) CFG(5, 2) CFG(6, 2) CFG(7, 2) CFG(8, 2)
+    const int pick = glds_pick_tile(M, s.N, s.K);
+    printf("  glds_pick_tile -> ACC %d BC %d\n", pick & 15, 1 + (pick >> 4));
+#define CFG(a, n, b) if (!pick_only || pick == a + 16 * (b - 1)) one_cfg<a, EPI, n, b>(s, M, reps, A, B, bx, C, aux0, aux1, ep, ref, ra0, ra1);
+    CFG(1, 3, 1) CFG(2, 3, 1) CFG(3, 3, 1) CFG(4, 3, 1) CFG(5, 3, 1) CFG(6, 3, 1) CFG(7, 3, 1) CFG(8, 3, 1)
+    CFG(1, 2, 2) CFG(2, 2, 2) CFG(3, 2, 2) CFG(4, 2, 2) CFG(5, 2, 2) CFG(6, 2, 2) CFG(7, 2, 2) CFG(8, 2, 2)
 #undef CFG
     hipFree(A); hipFree(B); hipFree(Bx); hipFree(R); hipFree(bias); hipFree(bw); hipFree(bb); hipFree(bm); hipFree(bv);
     hipFree(C); hipFree(aux0); hipFree(aux1);

@@ -16,12 +16,13 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/nsc.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "nsc_gemm_glds.h"
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -758,6 +759,16 @@ template <bool AKM, bool BKM>
 void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
           const float *bias, int accumulate, int splits, float *slabs)
 {
+    if (!AKM && !BKM && splits <= 1 && (bias || !accumulate)) {
+        // the projections of the training forward: the inference forward's LDS-DMA GEMM (same chain per output element as
+        // gemm_gen_kernel, same (acc + bias) + C order); anything it cannot take (unaligned operands) falls through
+        GemmEpi ep = {};
+        ep.bias = bias;
+        if (accumulate) { ep.resid = C; ep.ldr = ldc; }
+        const bool ok = bias ? launch_glds<2>(st, A, lda, B, ldb, nullptr, M, N, N, K, C, ldc, ep)
+                             : launch_glds<0>(st, A, lda, B, ldb, nullptr, M, N, N, K, C, ldc, ep);
+        if (ok) return;
+    }
     dim3 grid((N + 63) / 64, (M + 31) / 32, splits);
     if (splits <= 1) {
         hipLaunchKernelGGL((gemm_gen_kernel<AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, K, K, C, ldc,

@@ -225,6 +225,11 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
 #define NSC_GAT_LDS_TILED 4u
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream);
+/* Which tile the default (LDS-DMA) GEMM takes for C[M,N] = A[M,K] B[N,K]^T -- host function, no device work: rows and
+ * columns of a workgroup tile, its LDS bytes and the number of workgroups (a grid of at most 256 is one round on the
+ * 256 CUs).  Returns NSC_OK, or NSC_EINVAL for non-positive sizes / K not a multiple of 16. */
+int nsc_gat_gemm_tile(int32_t M, int32_t N, int32_t K, int32_t *tile_rows, int32_t *tile_cols, int32_t *lds_bytes,
+                      int64_t *workgroups);
 
 /* ------------------------------------------------------------------------------------------
  * Training step of the GNN (BASELINE configs[4]): model.train(); emb = model(graph);

@@ -1004,6 +1004,19 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     return nsc_gat_forward_ex(m, g, x, edge_attr, out, alpha_out, ws, ws_bytes, 0u, stream_);
 }
 
+int nsc_gat_gemm_tile(int32_t M, int32_t N, int32_t K, int32_t *tile_rows, int32_t *tile_cols, int32_t *lds_bytes,
+                      int64_t *workgroups)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 15)) return NSC_EINVAL;
+    const int t = glds_pick_tile(M, N, K);
+    const int acc = t & 15, bc = 1 + (t >> 4), nst = bc == 1 ? 3 : 2;
+    if (tile_rows) *tile_rows = 16 * acc;
+    if (tile_cols) *tile_cols = 64 * bc;
+    if (lds_bytes) *lds_bytes = nst * (16 * acc + 64 * bc) * 256;
+    if (workgroups) *workgroups = (int64_t)((N + 64 * bc - 1) / (64 * bc)) * ((M + 16 * acc - 1) / (16 * acc));
+    return NSC_OK;
+}
+
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream_)
 {

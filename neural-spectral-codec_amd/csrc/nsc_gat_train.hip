@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/nsc.h"
 

@@ -364,8 +364,11 @@ bool launch_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, in
 // Tile of the stand-alone GEMM, (16 ACC) rows x (64 BC) columns: the grid should be ONE round of at most a workgroup per CU
 // (256), and among such grids the one with the least work per workgroup; when no tile gives one round, the cost is
 // rounds x (MFMA time of a tile + what a round costs besides: first operand round trip, epilogue, ramp).  BC = 2 (two
-// stages: 2 x (16 ACC + 128) x 256 B of LDS) is what gives output_proj at 4 541 rows one round (252 tiles of 128 x 128
-// instead of two rounds of 468 tiles of 128 x 64).  Returns ACC + 16 (BC - 1).
+// stages: 2 x (16 ACC + 128) x 256 B of LDS) gives mid-sized wide outputs one round (output_proj at 2 500 rows: 224 tiles
+// of 80 x 128, 17.0 us against 21.9 for round 2's kernel).  At 4 541 rows output_proj would need 128 x 128 tiles for that
+// (252 of them): measured 26.1 us against 26.5 for two rounds of 128 x 64 -- and 64 + 80 accumulator and operand registers
+// plus the compiler's copies do not fit 256: the instantiation spilled inside the loop, so it is not offered
+// (tests/test_abi_cpu.py::test_glds_gemm_code_objects holds every instantiation to 0 B of scratch).  Returns ACC + 16 (BC - 1).
 inline int glds_pick_tile(int M, int N, int K)
 {
     const long long nch = (K + 63) / 64;
@@ -373,7 +376,7 @@ inline int glds_pick_tile(int M, int N, int K)
     long long best_cost = -1;
     for (int bc = 1; bc <= 2; ++bc) {
         const long long ncb = (N + 64 * bc - 1) / (64 * bc);
-        for (int a = 1; a <= 8; ++a) {
+        for (int a = 1; a <= (bc == 1 ? 8 : 7); ++a) {             // 128 x 128 tiles (a = 8, bc = 2) do not fit 256 registers: they spill
             const long long tiles = ncb * ((M + 16 * a - 1) / (16 * a));
             const long long rounds = (tiles + 255) / 256;
             const long long cost = rounds * (a * bc * nch * 512 + 3000);    // cycles: 16 MFMAs of 32 per chunk and accumulator
@@ -396,7 +399,8 @@ bool launch_glds(hipStream_t st, const float *A, int lda, const float *B, int ld
     case 16 + a: return launch_glds_cfg<a, EPI, 2, 2>(st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep);
     switch (glds_pick_tile(M, N, K)) {
         NSC_GLDS_CASE(1) NSC_GLDS_CASE(2) NSC_GLDS_CASE(3) NSC_GLDS_CASE(4)
-        NSC_GLDS_CASE(5) NSC_GLDS_CASE(6) NSC_GLDS_CASE(7) NSC_GLDS_CASE(8)
+        NSC_GLDS_CASE(5) NSC_GLDS_CASE(6) NSC_GLDS_CASE(7)
+        case 8: return launch_glds_cfg<8, EPI, 3, 1>(st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep);
     }
 #undef NSC_GLDS_CASE
     return false;

@@ -32,6 +32,27 @@ def test_header_symbols_exported(lib):
     assert declared == set(_lib.SYMBOLS), "ctypes binding out of sync with include/nsc.h"
 
 
+def test_gemm_tile_choice(lib):
+    """Which tile the LDS-DMA GEMM takes is a host decision (nsc_gat_gemm_tile, shared with the launcher): at BASELINE
+    configs[2] (4 541 keyframes) every projection is ONE round of at most 256 workgroups; for any shape the tile fits the
+    160 KB of a CU and covers the output."""
+    def tile(M, N, K):
+        r, c, l, w = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        assert lib.nsc_gat_gemm_tile(M, N, K, C.byref(r), C.byref(c), C.byref(l), C.byref(w)) == 0
+        return r.value, c.value, l.value, w.value
+    assert tile(4541, 256, 800) == (80, 64, 3 * 144 * 256, 228)        # input_proj: 57 x 4 tiles
+    assert tile(4541, 258, 256) == (96, 64, 3 * 160 * 256, 240)        # lin + 2 attention columns: 48 x 5
+    assert tile(4541, 800, 256) == (128, 64, 3 * 192 * 256, 468)       # output_proj: two rounds of 36 x 13 (128 x 128 tiles spill)
+    assert tile(1024, 256, 800) == (16, 64, 3 * 80 * 256, 256)         # the bench's GNN: one 16 x 16 block per wave
+    for M in (1, 15, 16, 17, 100, 1023, 1024, 1025, 2500, 4541, 9000, 50000):
+        for N, K in ((256, 800), (258, 256), (800, 256), (64, 48), (80, 64), (1024, 1024), (3, 16)):
+            r, c, l, w = tile(M, N, K)
+            assert r % 16 == 0 and 16 <= r <= 128 and c in (64, 128) and l <= 160 * 1024
+            assert w == -(-M // r) * -(-N // c)
+    assert lib.nsc_gat_gemm_tile(0, 256, 256, None, None, None, None) == -1
+    assert lib.nsc_gat_gemm_tile(16, 256, 40, None, None, None, None) == -1       # K not a multiple of 16
+
+
 def test_argument_validation_without_gpu(lib):
     from neural_spectral_codec_amd import _lib
     p = _lib.EncParams()
@@ -149,6 +170,41 @@ def test_coresident_register_budget(lib, tmp_path):
     assert len(co) >= 4, sorted(kernels)
     for k, (vg, sc) in co.items():
         assert vg <= 56 and sc == 0, f"{k}: {vg} VGPRs, {sc} B scratch"
+
+
+def test_glds_gemm_code_objects(lib, tmp_path):
+    """gemm_glds_kernel (512 threads = two waves per SIMD, one of each kind): every instantiation fits 256 registers per
+    lane without scratch (the 128 x 128 tile did not: it is not instantiated), stages by LDS-DMA only (no wide ds_write),
+    and the three-stage form keeps its counted wait -- `s_waitcnt vmcnt(N > 0)` directly followed by a raw `s_barrier`
+    (validated: HIP 7.2, AMD clang 22.0.0git roc-7.2.0)."""
+    llvm, objs = _code_objects(tmp_path)
+    seen = 0
+    for f in objs:
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", f], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split(".agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name or "gemm_glds_kernel" not in name.group(1):
+                continue
+            ag = int(re.match(r":\s+(\d+)", blk).group(1))
+            vg = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+            sc = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+            assert vg <= 256 and sc == 0, f"{name.group(1)}: {vg} VGPRs (+{ag} AGPRs), {sc} B scratch"
+            seen += 1
+        dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", f], check=True, capture_output=True,
+                             text=True).stdout
+        for m in re.finditer(r"^[0-9a-f]+ <(\S*gemm_glds_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, flags=re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
+            dma = [t for t in ins if t.startswith("global_load_lds_dwordx4")]
+            mf = [t for t in ins if t.startswith("v_mfma_f32_16x16x4")]
+            assert dma and mf, f"{name}: {len(dma)} LDS-DMA loads, {len(mf)} MFMAs"
+            # staging is LDS-DMA only: the epilogue's accumulator stores are the kernel's only LDS writes (one dword each)
+            assert not [t for t in ins if re.match(r"ds_write(2)?_b(64|96|128)", t)], f"{name}: wide ds_write (register staging crept in)"
+            # the staging waves' counted wait survives: vmcnt(N > 0) directly in front of a raw s_barrier
+            counted = [i for i, t in enumerate(ins) if re.match(r"s_waitcnt vmcnt\([1-9]\d*\)$", t) and ins[i + 1].startswith("s_barrier")]
+            if "ELi3ELi1EE" in name:                           # three stages: one chunk stays in flight across the barrier
+                assert counted, f"{name}: no counted vmcnt wait in front of a barrier"
+    assert seen >= 45, seen                                   # (8 + 7) tiles x 3 epilogues
 
 
 def test_stream_loop_isa(lib, tmp_path):

@@ -132,7 +132,7 @@ static void shape(const Shape &s, int M, int reps, int pick_only)
     printf("  glds_pick_tile -> ACC %d BC %d\n", pick & 15, 1 + (pick >> 4));
 #define CFG(a, n, b) if (!pick_only || pick == a + 16 * (b - 1)) one_cfg<a, EPI, n, b>(s, M, reps, A, B, bx, C, aux0, aux1, ep, ref, ra0, ra1);
     CFG(1, 3, 1) CFG(2, 3, 1) CFG(3, 3, 1) CFG(4, 3, 1) CFG(5, 3, 1) CFG(6, 3, 1) CFG(7, 3, 1) CFG(8, 3, 1)
-    CFG(1, 2, 2) CFG(2, 2, 2) CFG(3, 2, 2) CFG(4, 2, 2) CFG(5, 2, 2) CFG(6, 2, 2) CFG(7, 2, 2) CFG(8, 2, 2)
+    CFG(1, 2, 2) CFG(2, 2, 2) CFG(3, 2, 2) CFG(4, 2, 2) CFG(5, 2, 2) CFG(6, 2, 2) CFG(7, 2, 2)
 #undef CFG
     hipFree(A); hipFree(B); hipFree(Bx); hipFree(R); hipFree(bias); hipFree(bw); hipFree(bb); hipFree(bm); hipFree(bv);
     hipFree(C); hipFree(aux0); hipFree(aux1);

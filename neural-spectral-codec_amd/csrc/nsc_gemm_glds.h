@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
     constexpr int BM = 16 * ACC, BN = 64 * BC, ROWS = BM + BN, NPW = ROWS / 16;   // NPW: LDS-DMA pieces (4 rows) per staging wave and chunk
     constexpr int STAGE = ROWS * 64;                                // floats per stage
     constexpr int LD = BN + 4;                                      // epilogue staging stride
-    static_assert(BM * LD <= NST * STAGE, "the epilogue tile reuses the stages");
+    static_assert(BM * LD + 3 * BN <= NST * STAGE, "the epilogue tile (+ the folded BatchNorm of its columns) reuses the stages");
     extern __shared__ __attribute__((aligned(1024))) float gemm_lds[];   // the ONLY LDS object of the kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,13 +98,13 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
     const bool active = n0 + wave * 16 * BC < N;      // a computing wave whose columns all lie beyond N has nothing to do
 
     // epilogue operands: the bias loads of the computing waves go out at once and stay in flight across the main loop (their
-    // barriers do not wait for vector memory); the staging waves fetch theirs after the last chunk.  The 20 BatchNorm loads
-    // of EPI 1 stay behind the second epilogue barrier in every wave (ahead of the loop, or ahead of the barriers, they
-    // measured +0.8 us on input_proj)
+    // barriers do not wait for vector memory); the staging waves fetch theirs after the last chunk.  The BatchNorm operands
+    // of EPI 1 are folded by the staging waves after their last chunk and handed over through LDS (in every wave ahead of the
+    // loop, or ahead of the barriers, their 20 loads per thread measured +0.8 us on input_proj)
     const int c4t = tid & (BN / 4 - 1);
     const int cg = n0 + 4 * c4t;
-    float bias[4] = {0.f, 0.f, 0.f, 0.f}, raw_var[4] = {1.f, 1.f, 1.f, 1.f}, raw_w[4] = {1.f, 1.f, 1.f, 1.f};
-    float raw_b[4] = {0.f, 0.f, 0.f, 0.f}, raw_mean[4] = {0.f, 0.f, 0.f, 0.f};
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    float bn_pre[3] = {1.f, 0.f, 0.f};                             // EPI 1: scale, shift, bias of column n0 + tid - 256 (staging waves)
     const bool vec = (cg + 3 < n_main) && !(ldc & 3) && !(reinterpret_cast<unsigned long long>(C) & 15) &&
                      (EPI != 2 || !ep.resid || (!(ep.ldr & 3) && !(reinterpret_cast<unsigned long long>(ep.resid) & 15)));
     constexpr int RPP = 2048 / BN;                                 // rows per epilogue pass of the 512 threads (a float4 each)
@@ -117,7 +117,6 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
         for (int j = 0; j < 4; ++j) {
             const int col = (cg + j < N) ? cg + j : N - 1;
             if (EPI != 0) bias[j] = ep.bias[col];
-            if (EPI == 1) { raw_var[j] = ep.bn_var[col]; raw_w[j] = ep.bn_w[col]; raw_b[j] = ep.bn_b[col]; raw_mean[j] = ep.bn_mean[col]; }
         }
     };
     // The residual quads are fetched right after a wave's last chunk: the staging waves are done a chunk before the
@@ -190,6 +189,17 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (EPI != 1) load_epilogue();
         load_residual();
+        if (EPI == 1 && tid < 256 + BN) {
+            // BatchNorm (eval) of this tile's columns, folded to a scale and a shift by the staging waves, idle from their last
+            // chunk on; handed over through LDS behind the tile (the 20 loads per thread that every wave used to issue after
+            // the second epilogue barrier were an exposed round trip).  torch batch_norm eval: alpha = invstd * weight,
+            // beta = bias - mean * alpha.
+            const int cl = tid - 256, col = (n0 + cl < N) ? n0 + cl : N - 1;
+            const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
+            bn_pre[0] = invstd * ep.bn_w[col];
+            bn_pre[1] = ep.bn_b[col] - ep.bn_mean[col] * bn_pre[0];
+            bn_pre[2] = ep.bias[col];
+        }
     } else {
         // ---- computing waves
         const int boff = (BM + 16 * BC * wave + r) * 64, aoff = r * 64;
@@ -282,6 +292,11 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
 
     // epilogue as in gemm_nt_kernel: the tile goes through LDS, rows leave as 256 contiguous bytes; all 8 waves store
     float *Cs = gemm_lds;
+    if (EPI == 1 && tid >= 256 && tid < 256 + BN) {
+        Cs[BM * LD + tid - 256] = bn_pre[0];
+        Cs[BM * LD + BN + tid - 256] = bn_pre[1];
+        Cs[BM * LD + 2 * BN + tid - 256] = bn_pre[2];
+    }
     if (wave8 < 4 && active) {
 #pragma unroll
         for (int h = 0; h < ACC; ++h)
@@ -294,13 +309,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
     __syncthreads();
     float bn_scale[4] = {1.f, 1.f, 1.f, 1.f}, bn_shift[4] = {0.f, 0.f, 0.f, 0.f};
     if (EPI == 1) {
-        load_epilogue();
+        const float *pre = Cs + BM * LD;                           // 3 x BN floats behind the tile
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                              // torch batch_norm eval: alpha = invstd * weight, beta = bias - mean * alpha
-            const float invstd = 1.0f / sqrtf(raw_var[j] + ep.bn_eps);
-            bn_scale[j] = invstd * raw_w[j];
-            bn_shift[j] = raw_b[j] - raw_mean[j] * bn_scale[j];
-        }
+        for (int j = 0; j < 4; ++j) { bn_scale[j] = pre[4 * c4t + j]; bn_shift[j] = pre[BN + 4 * c4t + j]; bias[j] = pre[2 * BN + 4 * c4t + j]; }
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {

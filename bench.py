@@ -172,7 +172,7 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
         inner.coresident = was
         tf = GAT_FLOP_PER_NODE * 4541 / (gat[4541] * 1e-6) / 1e12
         out["roofline_gat"] = {
-            "bound": "mfma_f32", "kernel": "gemm_nt_kernel (800->256, 3 x 256->256, 256->800) + gat_aggregate_kernel",
+            "bound": "mfma_f32", "kernel": "gemm_glds_kernel (800->256, 3 x 256->256, 256->800) + gat_aggregate_kernel",
             "workload": "BASELINE.json configs[2]: 4541 keyframes, 18158 temporal edges, edge_dim=2, eval mode, one GPU",
             "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
             "flop_per_forward": GAT_FLOP_PER_NODE * 4541, "forward_us": gat[4541],

@@ -18,8 +18,8 @@ PEAK = 157.3e12
 
 
 def key(name):
-    if "gemm_nt" in name:
-        m = re.search(r"gemm_nt\w*kernel<\s*\d+,\s*(\d+)", name)     # <ACC, EPI[, ACN]>: the role is the EPI argument
+    if "gemm_nt" in name or "gemm_glds" in name:
+        m = re.search(r"gemm_(?:nt|glds)\w*kernel<\s*\d+,\s*(\d+)", name)     # <ACC, EPI, ...>: the role is the EPI argument
         if m and m.group(1) + ">" in FLOP:
             return m.group(1) + ">"
     if "gat_aggregate" in name:
@@ -44,7 +44,8 @@ for r in stats:
         print(f"| `gat_aggregate_kernel<1,8,true>` | attention softmax + aggregation (x3 per forward) | {calls} | {avg:.2f} | {mn:.2f} | - | - | - |")
     else:
         tf = FLOP[k] / (avg * 1e-6) / 1e12
-        print(f"| `gemm_nt_kernel<*,{k[0]}>` | {NAME[k]}{' (x3 per forward)' if k == '0>' else ''} | {calls} | {avg:.2f} | {mn:.2f} | "
+        base = re.sub(r"<.*", "", r["Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
+        print(f"| `{base}<*,{k[0]}>` | {NAME[k]}{' (x3 per forward)' if k == '0>' else ''} | {calls} | {avg:.2f} | {mn:.2f} | "
               f"{FLOP[k] / 1e9:.3f} | {tf:.1f} | {tf / 157.3 * 100:.1f} |")
 fl = FLOP["1>"] + 3 * FLOP["0>"] + FLOP["2>"]
 print(f"\nSum of kernel time per forward: {tot:.1f} us for {fl / 1e9:.2f} GFLOP of MFMA work = "
@@ -72,7 +73,7 @@ for k in ("1>", "0>", "2>"):
     util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0)
     wi = c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1)
     wa = c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1)
-    print(f"| `gemm_nt_kernel<*,{k[0]}>` | {flop / 1e9:.3f} G | {c['SQ_VALU_MFMA_BUSY_CYCLES']:.3g} | "
+    print(f"| `gemm_glds_kernel<*,{k[0]}>` | {flop / 1e9:.3f} G | {c['SQ_VALU_MFMA_BUSY_CYCLES']:.3g} | "
           f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / n_mfma:.1f} | {gui:.0f} | {util * 100:.1f} % | {wi * 100:.0f} % | {wa * 100:.0f} % |")
 print("\n`SQ_INSTS_VALU_MFMA_MOPS_F32 x 512` reproduces the algorithmic FLOP count (padding rows of the last tile included); "
       "`SQ_VALU_MFMA_BUSY_CYCLES` is 32 cycles per `v_mfma_f32_16x16x4_f32`. `MfmaUtil` is rocprofv3's own derived formula "

@@ -153,7 +153,7 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
         inner = getattr(model, "gnn", model)
         was = inner.coresident
         inner.coresident = False
-        gat = {}
+        gat, gat_graph = {}, {}
         for n in (4541, n_local):
             g = gm.synthetic_chain_graph(n, device=dev, seed=1)
             for _ in range(5):
@@ -169,6 +169,35 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
                 us = a.elapsed_time(b) / 50 * 1e3
                 best = us if best is None else min(best, us)
             gat[n] = best
+            # the same forward replayed as a captured hipGraph (what the pipelined step does with its GNN pass, DESIGN.md
+            # section 5): one graph launch instead of eight kernel launches and their Python plumbing
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    model(g)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):
+                    model(g)
+                cg.replay()
+                torch.cuda.synchronize(dev)
+                bestg = None
+                for _ in range(3):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(50):
+                        cg.replay()
+                    b.record()
+                    torch.cuda.synchronize(dev)
+                    us = a.elapsed_time(b) / 50 * 1e3
+                    bestg = us if bestg is None else min(bestg, us)
+                gat_graph[n] = bestg
+                del cg
+            except Exception as ex:  # noqa: BLE001 -- a side measurement must not take the bench down
+                gat_graph[n] = None
+                print(f"[bench] hipGraph replay of the GAT forward not measured ({type(ex).__name__}: {ex})", file=sys.stderr)
         inner.coresident = was
         tf = GAT_FLOP_PER_NODE * 4541 / (gat[4541] * 1e-6) / 1e12
         out["roofline_gat"] = {
@@ -176,7 +205,8 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
             "workload": "BASELINE.json configs[2]: 4541 keyframes, 18158 temporal edges, edge_dim=2, eval mode, one GPU",
             "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
             "flop_per_forward": GAT_FLOP_PER_NODE * 4541, "forward_us": gat[4541],
-            "forward_us_at_step_size": gat[n_local], "traffic": None,
+            "forward_us_at_step_size": gat[n_local], "forward_us_as_hipgraph": gat_graph.get(4541),
+            "forward_us_at_step_size_as_hipgraph": gat_graph.get(n_local), "traffic": None,
             "note": "whole forward (8 launches) by HIP events; per-kernel durations and the MFMA counters "
                     "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32) are in profiles/r03_gat_n4541_*",
         }

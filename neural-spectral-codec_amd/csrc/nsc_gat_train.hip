@@ -456,14 +456,75 @@ struct AttBwdA {
     int N, H, edge_dim;
 };
 
+// CH = ceil(H / 256): float4 chunks per lane.  Round 3: the common case (in-degree <= 64) keeps dY_i in registers, fetches
+// 8 neighbour rows of G at a time as float4 (all in flight before the first reduction) and computes every <dY_i, g_j> ONCE
+// (lane e keeps entry e's value); the first form walked the entries twice, one dependent round trip chain per entry
+// (17.5 us at 4 541 keyframes).
+template <int CH>
 __global__ __launch_bounds__(256) void att_bwd_target_kernel(AttBwdA a)
 {
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.N) return;
-    const int beg = a.row_ptr[i], end = a.row_ptr[i + 1];
+    const int beg = a.row_ptr[i], end = a.row_ptr[i + 1], deg = end - beg;
     TrainAgg t;   // view for edge_raw()
     t.src = a.src; t.eid = a.eid; t.a_src = a.a_src; t.a_dst = a.a_dst; t.edge_attr = a.edge_attr;
     t.loop_attr = a.loop_attr; t.v = a.v; t.edge_dim = a.edge_dim;
+    if (deg <= 64) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dy[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = 4 * lane + 256 * k;
+            dy[k] = (c < a.H) ? *reinterpret_cast<const f32x4 *>(a.dY + (long long)i * a.H + c) : zero;
+        }
+        const int e_l = beg + lane;
+        const bool have = e_l < end;
+        const int j_l = have ? a.src[e_l] : 0;
+        const float al_l = have ? a.alpha[e_l] : 0.0f;
+        const unsigned long long seed = a.seed.get();
+        float da = 0.0f;                                          // <dY_i, g_j> of entry `lane`, through the dropout mask
+        for (int t0 = 0; t0 < deg; t0 += 8) {
+            f32x4 g[8][CH];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jt = __shfl(j_l, (t0 + u) & 63);
+                const float *row = a.G + (long long)((t0 + u < deg) ? jt : i) * a.H;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int c = 4 * lane + 256 * k;
+                    g[u][k] = (c < a.H) ? *reinterpret_cast<const f32x4 *>(row + c) : zero;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u >= deg) break;                         // wave-uniform
+                float d = 0.0f;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    d = __builtin_fmaf(dy[k].x, g[u][k].x, d);
+                    d = __builtin_fmaf(dy[k].y, g[u][k].y, d);
+                    d = __builtin_fmaf(dy[k].z, g[u][k].z, d);
+                    d = __builtin_fmaf(dy[k].w, g[u][k].w, d);
+                }
+                const float sum = wave_sumf(d) * keep_scale(a.p, seed, a.stream, (unsigned long long)(beg + t0 + u));
+                if (lane == t0 + u) da = sum;
+            }
+        }
+        float inner = 0.0f;                                       // sum_e alpha_e dalpha_e, in entry order
+        for (int tt = 0; tt < deg; ++tt) inner += __shfl(al_l, tt) * __shfl(da, tt);
+        float dr = 0.0f;
+        if (have) {
+            int j;
+            const float raw = edge_raw(t, i, e_l, j);
+            const float dl = al_l * (da - inner);                 // softmax backward
+            dr = raw > 0.0f ? dl : a.slope * dl;                  // leaky-relu backward
+            a.draw[e_l] = dr;
+        }
+        float dd = 0.0f;
+        for (int tt = 0; tt < deg; ++tt) dd += __shfl(dr, tt);
+        if (lane == 0) a.da_dst[i] = dd;
+        return;
+    }
     auto dalpha = [&](int e) -> float {                       // <dY_i, g_j> through the dropout mask
         const int j = a.src[e];
         float d = 0.0f;
@@ -497,22 +558,77 @@ struct AttBwdB {
     int N, H;
 };
 
+// CH = ceil(H / 256).  Round 3: a lane fetches ONE entry of the source's list (its edge index, draw, alpha through the
+// dropout mask, target), the values travel by shuffle, and the dY rows come 8 at a time as float4; every column still adds its
+// terms in list order (same bits as the first form, which re-read the list once per 64 columns, a dependent chain per entry).
+template <int CH>
 __global__ __launch_bounds__(256) void att_bwd_source_kernel(AttBwdB a)
 {
     const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= a.N) return;
     const int beg = a.t_ptr[j], end = a.t_ptr[j + 1];
+    const unsigned long long seed = a.seed.get();
     float das = 0.0f;
-    for (int t = beg; t < end; ++t) das += a.draw[a.t_entry[t]];
+    for (int c0 = beg; c0 < end; c0 += 64) {                      // da_src[j] = sum of draw over the list, in list order
+        const int tl = c0 + lane;
+        const float dl = (tl < end) ? a.draw[a.t_entry[tl]] : 0.0f;
+        const int cnt = min(64, end - c0);
+        for (int tt = 0; tt < cnt; ++tt) das += __shfl(dl, tt);
+    }
     const float dad = a.da_dst[j];
-    for (int c = lane; c < a.H; c += 64) {
-        float acc = das * a.att_src[c] + dad * a.att_dst[c];
-        for (int t = beg; t < end; ++t) {
-            const int e = a.t_entry[t];
-            const float al = a.alpha[e] * keep_scale(a.p, a.seed.get(), a.stream, (unsigned long long)e);
-            acc = __builtin_fmaf(al, a.dY[(long long)a.tgt[e] * a.H + c], acc);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = 4 * lane + 256 * k;
+        acc[k] = zero;
+        if (c < a.H) {
+            const f32x4 s1 = *reinterpret_cast<const f32x4 *>(a.att_src + c), s2 = *reinterpret_cast<const f32x4 *>(a.att_dst + c);
+            acc[k].x = das * s1.x + dad * s2.x; acc[k].y = das * s1.y + dad * s2.y;
+            acc[k].z = das * s1.z + dad * s2.z; acc[k].w = das * s1.w + dad * s2.w;
         }
-        a.dG[(long long)j * a.H + c] = acc;
+    }
+    for (int c0 = beg; c0 < end; c0 += 64) {
+        const int tl = c0 + lane;
+        float al_l = 0.0f;
+        int tg_l = j;
+        if (tl < end) {
+            const int e = a.t_entry[tl];
+            al_l = a.alpha[e] * keep_scale(a.p, seed, a.stream, (unsigned long long)e);
+            tg_l = a.tgt[e];
+        }
+        const int cnt = min(64, end - c0);
+        for (int t0 = 0; t0 < cnt; t0 += 8) {
+            f32x4 r[8][CH];
+            float al[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                al[u] = __shfl(al_l, (t0 + u) & 63);
+                const int tg = __shfl(tg_l, (t0 + u) & 63);
+                const float *row = a.dY + (long long)((t0 + u < cnt) ? tg : j) * a.H;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int c = 4 * lane + 256 * k;
+                    r[u][k] = (c < a.H) ? *reinterpret_cast<const f32x4 *>(row + c) : zero;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u >= cnt) break;                         // wave-uniform
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    acc[k].x = __builtin_fmaf(al[u], r[u][k].x, acc[k].x);
+                    acc[k].y = __builtin_fmaf(al[u], r[u][k].y, acc[k].y);
+                    acc[k].z = __builtin_fmaf(al[u], r[u][k].z, acc[k].z);
+                    acc[k].w = __builtin_fmaf(al[u], r[u][k].w, acc[k].w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = 4 * lane + 256 * k;
+        if (c < a.H) *reinterpret_cast<f32x4 *>(a.dG + (long long)j * a.H + c) = acc[k];
     }
     if (lane == 0) a.da_src[j] = das;
 }
@@ -756,19 +872,46 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     return w;
 }
 
+// out[c * rows + r] = in[r * ld + c]: the (K, N) weight of a dX = dY W product as the (N, K) operand the NT GEMM takes
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int rows, int cols, int ld,
+                                                        float *__restrict__ out)
+{
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) t[ty + 8 * i][tx] = in[(long long)r * ld + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) out[(long long)c * rows + r] = t[tx][ty + 8 * i];
+    }
+}
+
+// slabs: split-K slabs of the weight-gradient products; for a single-slice product with a k-major B (dX = dY W) the same
+// buffer, free between two weight-gradient products of the stream, takes the transposed weight.
 template <bool AKM, bool BKM>
 void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
           const float *bias, int accumulate, int splits, float *slabs)
 {
-    if (!AKM && !BKM && splits <= 1 && (bias || !accumulate)) {
-        // the projections of the training forward: the inference forward's LDS-DMA GEMM (same chain per output element as
-        // gemm_gen_kernel, same (acc + bias) + C order); anything it cannot take (unaligned operands) falls through
+    if (!AKM && splits <= 1 && (!BKM || (slabs && !(K & 15) && !(reinterpret_cast<unsigned long long>(slabs) & 15)))) {
+        // the projections of the training forward, and the dX = dY W products of the backward through a transposed copy of
+        // the weight (0.8 MB at most: a 3 us kernel): the inference forward's LDS-DMA GEMM -- same chain per output element
+        // as gemm_gen_kernel, same (acc + bias) + C order; anything it cannot take (unaligned operands) falls through
+        const float *Bn = B;
+        int ldn = ldb;
+        if (BKM) {
+            hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, st, B, K, N, ldb, slabs);
+            Bn = slabs;
+            ldn = K;
+        }
         GemmEpi ep = {};
         ep.bias = bias;
         if (accumulate) { ep.resid = C; ep.ldr = ldc; }
-        const bool ok = bias ? launch_glds<2>(st, A, lda, B, ldb, nullptr, M, N, N, K, C, ldc, ep)
-                             : launch_glds<0>(st, A, lda, B, ldb, nullptr, M, N, N, K, C, ldc, ep);
-        if (ok) return;
+        if (launch_glds<2>(st, A, lda, Bn, ldn, nullptr, M, N, N, K, C, ldc, ep)) return;
     }
     dim3 grid((N + 63) / 64, (M + 31) / 32, splits);
     if (splits <= 1) {
@@ -933,7 +1076,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr, acc);
     gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, acc, splits, slabs);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
-    gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, nullptr);   // dh_L = dOut W_out
+    gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, slabs);   // dh_L = dOut W_out
     const bool res_id = m->residual && Din == Dout, res_proj = m->residual && Din != Dout;
     if (res_proj) {                // residual_proj: dW_res = dOut^T x, db_res = colsum dOut      model.py:147-149
         if (!gr->res_w || !gr->res_b) return NSC_EINVAL;
@@ -946,7 +1089,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         if (res_id) {
             if (hipMemcpyAsync(gr->x, grad_out, (size_t)N * Din * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
         } else if (res_proj) {
-            gemm<false, true>(st, grad_out, Dout, m->res_w, Din, N, Din, Dout, gr->x, Din, nullptr, 0, 1, nullptr);
+            gemm<false, true>(st, grad_out, Dout, m->res_w, Din, N, Din, Dout, gr->x, Din, nullptr, 0, 1, slabs);
         } else {
             if (hipMemsetAsync(gr->x, 0, (size_t)N * Din * 4, st) != hipSuccess) return NSC_ELAUNCH;
         }
@@ -981,13 +1124,23 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         A.draw = F(w.draw); A.da_dst = F(w.da_dst);
         A.slope = m->negative_slope; A.p = cfg->dropout_p; A.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; A.stream = 100u + l;
         A.N = N; A.H = H; A.edge_dim = m->edge_dim;
-        hipLaunchKernelGGL(att_bwd_target_kernel, dim3((N + 3) / 4), dim3(256), 0, st, A);
+        switch ((H + 255) / 256) {
+        case 1: hipLaunchKernelGGL(att_bwd_target_kernel<1>, dim3((N + 3) / 4), dim3(256), 0, st, A); break;
+        case 2: hipLaunchKernelGGL(att_bwd_target_kernel<2>, dim3((N + 3) / 4), dim3(256), 0, st, A); break;
+        case 3: hipLaunchKernelGGL(att_bwd_target_kernel<3>, dim3((N + 3) / 4), dim3(256), 0, st, A); break;
+        default: hipLaunchKernelGGL(att_bwd_target_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, st, A); break;
+        }
         AttBwdB Bk;
         Bk.t_ptr = g->t_ptr; Bk.t_entry = g->t_entry; Bk.tgt = g->tgt;
         Bk.alpha = alpha; Bk.dY = dY; Bk.draw = F(w.draw); Bk.da_dst = F(w.da_dst);
         Bk.att_src = Ly.att_src; Bk.att_dst = Ly.att_dst; Bk.dG = dG; Bk.da_src = F(w.da_src);
         Bk.p = cfg->dropout_p; Bk.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; Bk.stream = 100u + l; Bk.N = N; Bk.H = H;
-        hipLaunchKernelGGL(att_bwd_source_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Bk);
+        switch ((H + 255) / 256) {
+        case 1: hipLaunchKernelGGL(att_bwd_source_kernel<1>, dim3((N + 3) / 4), dim3(256), 0, st, Bk); break;
+        case 2: hipLaunchKernelGGL(att_bwd_source_kernel<2>, dim3((N + 3) / 4), dim3(256), 0, st, Bk); break;
+        case 3: hipLaunchKernelGGL(att_bwd_source_kernel<3>, dim3((N + 3) / 4), dim3(256), 0, st, Bk); break;
+        default: hipLaunchKernelGGL(att_bwd_source_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, st, Bk); break;
+        }
         // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
         colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr, acc);
         colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr, acc);
@@ -1006,7 +1159,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         }
         // g = h_l W^T :  dW = dG^T h_l ,  dh_l = dG W (+ residual path)
         gemm<true, true>(st, dG, H, hin, H, H, H, N, Gl.lin_w, H, nullptr, acc, splits, slabs);
-        gemm<false, true>(st, dG, H, Ly.lin_w, H, N, H, H, dh_prev, H, nullptr, 0, 1, nullptr);
+        gemm<false, true>(st, dG, H, Ly.lin_w, H, N, H, H, dh_prev, H, nullptr, 0, 1, slabs);
         if (has_res) hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh_prev, dh, NH);
         float *t = dh; dh = dh_prev; dh_prev = t;
     }
@@ -1022,7 +1175,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr, acc);
     gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, acc, splits, slabs);
     if (gr->x) {   // + dZ0 W_in
-        gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, nullptr);
+        gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, slabs);
     }
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = (cg + j < N) ? cg + j : N - 1;
-            if (EPI != 0) bias[j] = ep.bias[col];
+            if (EPI != 0) bias[j] = ep.bias ? ep.bias[col] : 0.0f;     // (EPI 2 without a bias: the training path's plain / accumulating GEMMs)
         }
     };
     // The residual quads are fetched right after a wave's last chunk: the staging waves are done a chunk before the

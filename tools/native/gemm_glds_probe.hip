@@ -1,7 +1,7 @@
 // Stand-alone A/B of the GEMM kernels of csrc/nsc_gat.hip on the three shapes of the GNN forward (input_proj 800 -> 256,
 // lin 256 -> 256 + 2 attention columns, output_proj 256 -> 800) at M rows:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I include -o /tmp/gemm_glds_probe tools/native/gemm_glds_probe.hip
-//   /tmp/gemm_glds_probe [M=4541] [reps=200]
+//   /tmp/gemm_glds_probe [M=4541] [reps=200] [picked tile only=0] [soak launches=0]
 // For every shape: the shipped dispatcher's choice of gemm_nt_kernel (reference result), then every ACC configuration
 // of gemm_glds_kernel -- output compared with the reference BIT FOR BIT (main columns and the two aux columns), time per launch
 // from HIP events over `reps` back-to-back launches.  Exit status 1 when any configuration differs.
@@ -27,6 +27,16 @@ static float *dalloc(size_t n, unsigned seed, float scale)
 }
 
 struct Shape { const char *name; int N, n_main, K, epi; };
+
+// soak: every launch's output compared on the device with the reference (bit patterns), mismatches counted
+__global__ void count_diff_kernel(const unsigned *a, const unsigned *b, size_t n, unsigned long long *cnt)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long d = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+    if (d) atomicAdd(cnt, d);
+}
+static int g_soak = 0;
 
 #ifndef NSC_GLDS_ABL
 #define NSC_GLDS_ABL 0            // ablation builds (-DNSC_GLDS_ABL=1 no MFMAs, 2 no refills, 3 both): timings only
@@ -73,6 +83,26 @@ static void one_cfg(const Shape &s, int M, int reps, const float *A, const float
         hipMemcpy(a0.data(), aux0, M * sizeof(float), hipMemcpyDeviceToHost);
         hipMemcpy(a1.data(), aux1, M * sizeof(float), hipMemcpyDeviceToHost);
         for (int i = 0; i < M; ++i) diff += (memcmp(&a0[i], &ra0[i], 4) != 0) + (memcmp(&a1[i], &ra1[i], 4) != 0);
+    }
+    if (g_soak > 0) {
+        // a new synchronisation structure (LDS-DMA in flight across raw barriers) is screened for races over many launches:
+        // a read that happened to precede its data would show as a differing element in SOME launch
+        float *Cref = nullptr;
+        unsigned long long *cnt = nullptr;
+        hipMalloc(&Cref, nc * sizeof(float)); hipMalloc(&cnt, 8);
+        hipMemcpy(Cref, ref.data(), nc * sizeof(float), hipMemcpyHostToDevice);
+        hipMemset(cnt, 0, 8);
+        for (int i = 0; i < g_soak; ++i) {
+            hipMemsetAsync(C, 0xff, nc * sizeof(float), 0);
+            launch_glds_cfg<ACC, EPI, NST, BC>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep);
+            hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, 0, reinterpret_cast<const unsigned *>(C),
+                               reinterpret_cast<const unsigned *>(Cref), nc, cnt);
+        }
+        unsigned long long bad = 0;
+        hipMemcpy(&bad, cnt, 8, hipMemcpyDeviceToHost);
+        printf("      soak: %d launches, differing elements in all of them together: %llu%s\n", g_soak, bad, bad ? "   <-- MISMATCH" : "");
+        if (bad) g_bad = 1;
+        hipFree(Cref); hipFree(cnt);
     }
     const float us = time_us([&] { launch_glds_cfg<ACC, EPI, NST, BC>(0, A, s.K, B, s.K, Bx, M, s.N, s.n_main, s.K, C, s.n_main, ep); }, reps);
     const long long tiles = (long long)((s.N + 64 * BC - 1) / (64 * BC)) * ((M + 16 * ACC - 1) / (16 * ACC));
@@ -142,6 +172,7 @@ int main(int argc, char **argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 4541, reps = argc > 2 ? atoi(argv[2]) : 200;
     const int pick_only = argc > 3 ? atoi(argv[3]) : 0;
+    g_soak = argc > 4 ? atoi(argv[4]) : 0;
     const Shape in = {"input_proj", 256, 256, 800, 1}, lin = {"lin", 258, 256, 256, 0}, outp = {"output_proj", 800, 800, 256, 2};
     shape<1>(in, M, reps, pick_only);
     shape<0>(lin, M, reps, pick_only);

@@ -76,50 +76,75 @@ __global__ __launch_bounds__(256) void gemm_gen_kernel(const float *__restrict__
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2] = {zero, zero};
 
-    for (int kb = k0; kb < k1; kb += BK) {
-        // ---- stage A tile (BM x BK) ----
+    // One 64-deep chunk in registers ahead of the one being multiplied (round 3: the first form fetched, staged, multiplied
+    // and only then fetched again -- with 4-5 chunks per split-K slab its time was the sum of their L2 round trips).
+    constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;
+    f32x4 ra[NA], rb[NB];
+    auto fetch = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < BM * BK / 4 / 256; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i;
+            f32x4 v = zero;
             if (!AKM) {
                 const int row = f >> 4, c4 = f & 15, gm = m0 + row, gk = kb + 4 * c4;
-                f32x4 v = zero;
                 if (gm < M && gk + 3 < k1) v = *reinterpret_cast<const f32x4 *>(A + (long long)gm * lda + gk);
                 else if (gm < M)
                     for (int j = 0; j < 4; ++j) if (gk + j < k1) v[j] = A[(long long)gm * lda + gk + j];
-                *reinterpret_cast<f32x4 *>(&As[row * LD + 4 * c4]) = v;
             } else {
                 const int kl = f / (BM / 4), m4 = f % (BM / 4), gk = kb + kl, gm = m0 + 4 * m4;
-                f32x4 v = zero;
                 if (gk < k1 && gm + 3 < M) v = *reinterpret_cast<const f32x4 *>(A + (long long)gk * lda + gm);
                 else if (gk < k1)
                     for (int j = 0; j < 4; ++j) if (gm + j < M) v[j] = A[(long long)gk * lda + gm + j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) As[(4 * m4 + j) * LD + kl] = v[j];
             }
+            ra[i] = v;
         }
-        // ---- stage B tile (BN x BK) ----
 #pragma unroll
-        for (int i = 0; i < BN * BK / 4 / 256; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int f = tid + 256 * i;
+            f32x4 v = zero;
             if (!BKM) {
                 const int row = f >> 4, c4 = f & 15, gn = n0 + row, gk = kb + 4 * c4;
-                f32x4 v = zero;
                 if (gn < N && gk + 3 < k1) v = *reinterpret_cast<const f32x4 *>(B + (long long)gn * ldb + gk);
                 else if (gn < N)
                     for (int j = 0; j < 4; ++j) if (gk + j < k1) v[j] = B[(long long)gn * ldb + gk + j];
-                *reinterpret_cast<f32x4 *>(&Bs[row * LD + 4 * c4]) = v;
             } else {
                 const int kl = f / (BN / 4), n4 = f % (BN / 4), gk = kb + kl, gn = n0 + 4 * n4;
-                f32x4 v = zero;
                 if (gk < k1 && gn + 3 < N) v = *reinterpret_cast<const f32x4 *>(B + (long long)gk * ldb + gn);
                 else if (gk < k1)
                     for (int j = 0; j < 4; ++j) if (gn + j < N) v[j] = B[(long long)gk * ldb + gn + j];
+            }
+            rb[i] = v;
+        }
+    };
+    auto stage = [&]() {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[(4 * n4 + j) * LD + kl] = v[j];
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + 256 * i;
+            if (!AKM) {
+                *reinterpret_cast<f32x4 *>(&As[(f >> 4) * LD + 4 * (f & 15)]) = ra[i];
+            } else {
+                const int kl = f / (BM / 4), m4 = f % (BM / 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(4 * m4 + j) * LD + kl] = ra[i][j];
             }
         }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + 256 * i;
+            if (!BKM) {
+                *reinterpret_cast<f32x4 *>(&Bs[(f >> 4) * LD + 4 * (f & 15)]) = rb[i];
+            } else {
+                const int kl = f / (BN / 4), n4 = f % (BN / 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * n4 + j) * LD + kl] = rb[i][j];
+            }
+        }
+    };
+    if (k0 < k1) fetch(k0);
+    for (int kb = k0; kb < k1; kb += BK) {
+        stage();
         __syncthreads();
+        if (kb + BK < k1) fetch(kb + BK);
 #pragma unroll
         for (int d = 0; d < BK / 16; ++d) {
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(&Bs[(wave * 16 + r) * LD + 16 * d + 4 * q]);
@@ -173,6 +198,8 @@ struct ColFinal {
     float eps, momentum;
     float *out_a, *out_b, *run_mean, *run_var;
     int acc_a, acc_b;          // mode 0: add to what out_a / out_b hold (gradient accumulation) instead of overwriting
+    float *copy_a, *copy_b;    // mode 0, nullable: the same sums also stored to (acc_copy: added into) a second vector -- the
+    int acc_copy;              // BatchNorm gradients are both an input of the next kernel and a parameter gradient
 };
 
 __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part, int R, int C, int c, int cx, int ry,
@@ -201,6 +228,8 @@ __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part
     if (f.mode == 0) {
         if (f.out_a) f.out_a[c] = f.acc_a ? f.out_a[c] + (float)a : (float)a;
         if (f.out_b) f.out_b[c] = f.acc_b ? f.out_b[c] + (float)b : (float)b;
+        if (f.copy_a) f.copy_a[c] = f.acc_copy ? f.copy_a[c] + (float)a : (float)a;
+        if (f.copy_b) f.copy_b[c] = f.acc_copy ? f.copy_b[c] + (float)b : (float)b;
     } else {
         const double mean = a / f.N;
         double var = b / f.N - mean * mean;
@@ -399,11 +428,70 @@ __device__ __forceinline__ float edge_raw(const TrainAgg &a, int i, int e, int &
     return l;
 }
 
+// CH = ceil(H / 256).  Round 3: in-degree <= 64 (every graph of the path) takes one logit per lane -- evaluated once, the first
+// form evaluated it three times -- and gathers 8 neighbour rows at a time as float4; per column the same terms in the same
+// order as the general form below.
+template <int CH>
 __global__ __launch_bounds__(256) void agg_train_kernel(TrainAgg a)
 {
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= a.N) return;
     const int beg = a.row_ptr[i], end = a.row_ptr[i + 1];
+    if (end - beg <= 64) {
+        const int deg = end - beg, e = beg + lane;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        int j = i;
+        float l = -INFINITY;
+        if (e < end) { l = edge_raw(a, i, e, j); l = l > 0.f ? l : a.slope * l; }
+        const float m = wave_maxf(l);
+        const float pe = (e < end) ? expf(l - m) : 0.0f;
+        const float s = wave_sumf(pe) + 1e-16f;                      // PyG softmax
+        float ald = 0.0f;
+        if (e < end) {
+            const float al = pe / s;
+            a.alpha[e] = al;                                          // saved for the backward (pre-dropout)
+            ald = al * keep_scale(a.p, a.seed.get(), a.stream, (unsigned long long)e);   // attention dropout
+        }
+        f32x4 acc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) acc[k] = zero;
+        for (int t0 = 0; t0 < deg; t0 += 8) {
+            f32x4 g[8][CH];
+            float at[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                at[u] = __shfl(ald, (t0 + u) & 63);
+                const int jt = __shfl(j, (t0 + u) & 63);
+                const float *row = a.G + (long long)((t0 + u < deg) ? jt : i) * a.H;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int c = 4 * lane + 256 * k;
+                    g[u][k] = (c < a.H) ? *reinterpret_cast<const f32x4 *>(row + c) : zero;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u >= deg) break;                             // wave-uniform
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    acc[k].x = __builtin_fmaf(at[u], g[u][k].x, acc[k].x);
+                    acc[k].y = __builtin_fmaf(at[u], g[u][k].y, acc[k].y);
+                    acc[k].z = __builtin_fmaf(at[u], g[u][k].z, acc[k].z);
+                    acc[k].w = __builtin_fmaf(at[u], g[u][k].w, acc[k].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = 4 * lane + 256 * k;
+            if (c < a.H) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + c);
+                *reinterpret_cast<f32x4 *>(a.y + (long long)i * a.H + c) =
+                    f32x4{acc[k].x + b.x, acc[k].y + b.y, acc[k].z + b.z, acc[k].w + b.w};
+            }
+        }
+        return;
+    }
     float m = -INFINITY;
     for (int e = beg + lane; e < end; e += 64) { int j; float l = edge_raw(a, i, e, j); l = l > 0.f ? l : a.slope * l; m = fmaxf(m, l); }
     m = wave_maxf(m);
@@ -711,14 +799,6 @@ __global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const float *__restri
     datt_edge[c] = accumulate ? datt_edge[c] + s : s;
 }
 
-// dst = src, or dst += src (gradient accumulation) for a short vector
-__global__ __launch_bounds__(256) void vec_store_kernel(float *__restrict__ dst, const float *__restrict__ src, int n,
-                                                        int accumulate)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
-}
-
 // transposed CSR (entries grouped by source) from the forward CSR
 __global__ __launch_bounds__(256) void tcsr_count_kernel(const int *__restrict__ row_ptr, const int *__restrict__ src,
                                                          int N, int *__restrict__ cnt, int *__restrict__ tgt)
@@ -929,13 +1009,14 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
 
 void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
                int N, int C, double *part, int mode, float eps, float momentum, float *out_a,
-               float *out_b, float *run_mean, float *run_var, int acc_a = 0, int acc_b = 0)
+               float *out_b, float *run_mean, float *run_var, int acc_a = 0, int acc_b = 0, float *copy_a = nullptr,
+               float *copy_b = nullptr, int acc_copy = 0)
 {
     int R = (N + 63) / 64;
     if (R > COLRED_MAXR) R = COLRED_MAXR;
     if (R < 1) R = 1;
     const int rows = (N + R - 1) / R;
-    const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var, acc_a, acc_b};
+    const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var, acc_a, acc_b, copy_a, copy_b, acc_copy};
     hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part);
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f);
 }
@@ -1029,7 +1110,12 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
         a.a_src = as; a.a_dst = ad; a.G = G; a.bias = Ly.bias; a.alpha = alpha; a.y = y;
         a.slope = m->negative_slope; a.p = cfg->dropout_p; a.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; a.stream = 100u + l;
         a.N = N; a.H = H; a.edge_dim = m->edge_dim;
-        hipLaunchKernelGGL(agg_train_kernel, dim3((N + 3) / 4), dim3(256), 0, st, a);
+        switch ((H + 255) / 256) {
+        case 1: hipLaunchKernelGGL(agg_train_kernel<1>, dim3((N + 3) / 4), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(agg_train_kernel<2>, dim3((N + 3) / 4), dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(agg_train_kernel<3>, dim3((N + 3) / 4), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(agg_train_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, st, a); break;
+        }
         colreduce(st, y, nullptr, y, nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum, mean, invstd,
                   upd ? const_cast<float *>(Ly.bn_mean) : nullptr, upd ? const_cast<float *>(Ly.bn_var) : nullptr);
         const int act = (l < L - 1);                                           // model.py:135-137
@@ -1108,9 +1194,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         // h_{l+1} = drop(relu(bn(y))) [+ h_l]  ->  dV, BatchNorm backward -> dY (in place in dv)
         hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
                            act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, NH, H, dv);
-        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
-        hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, Gl.bn_b, s1, H, acc);
-        hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, Gl.bn_w, s2, H, acc);
+        // s1 / s2 feed bn_bwd_apply AND are the BatchNorm parameter gradients: the reduction's finish stores both
+        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr, 0, 0, Gl.bn_b, Gl.bn_w, acc);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, y, mean, invstd, Ly.bn_w, s1, s2, NH, H, N, dv);
         float *dY = dv;
         // conv bias
@@ -1167,9 +1252,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     float *dv = F(w.dv), *s1 = F(w.s1), *s2 = F(w.s2);
     hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
                        m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, NH, H, dv);
-    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr);
-    hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, gr->in_bn_b, s1, H, acc);
-    hipLaunchKernelGGL(vec_store_kernel, dim3(blocks(H)), dim3(256), 0, st, gr->in_bn_w, s2, H, acc);
+    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr, 0, 0,
+              gr->in_bn_b, gr->in_bn_w, acc);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, s1, s2,
                        NH, H, N, dv);
     colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr, acc);

@@ -252,8 +252,11 @@ __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part
 __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__restrict__ P, const float *__restrict__ w,
                                                                 const float *__restrict__ Q, const float *__restrict__ qm,
                                                                 const float *__restrict__ qs, int N, int C,
-                                                                int rows_per_block, double *__restrict__ part)
+                                                                int rows_per_block, double *__restrict__ part,
+                                                                const float *__restrict__ w2)
 {
+    // w2 (with Q null): out_b[c] = sum_n P[n][c] * w2[n] -- the two attention-vector gradients of a layer read the same
+    // matrix with two weight vectors: one pass instead of two
     __shared__ double sa[256], sb[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -266,6 +269,8 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__r
             if (Q) {
                 if (qm) qv = (qv - m) * s;
                 b += (double)p * (double)qv;
+            } else if (w2) {
+                b += (double)(p * qv);                          // qv carries w2[n] here
             }
         };
         // 8 rows' loads go out before the first add (one row per round trip was an 8 us latency chain for 16 rows per
@@ -277,12 +282,12 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__r
             for (int u = 0; u < 8; ++u) {
                 pv[u] = P[(long long)(n + 4 * u) * C + c];
                 wv[u] = w ? w[n + 4 * u] : 1.0f;
-                qv[u] = Q ? Q[(long long)(n + 4 * u) * C + c] : 0.0f;
+                qv[u] = Q ? Q[(long long)(n + 4 * u) * C + c] : (w2 ? w2[n + 4 * u] : 0.0f);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) step(pv[u], wv[u], qv[u]);
         }
-        for (; n < n1; n += 4) step(P[(long long)n * C + c], w ? w[n] : 1.0f, Q ? Q[(long long)n * C + c] : 0.0f);
+        for (; n < n1; n += 4) step(P[(long long)n * C + c], w ? w[n] : 1.0f, Q ? Q[(long long)n * C + c] : (w2 ? w2[n] : 0.0f));
     }
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();
@@ -1010,14 +1015,14 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
 void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
                int N, int C, double *part, int mode, float eps, float momentum, float *out_a,
                float *out_b, float *run_mean, float *run_var, int acc_a = 0, int acc_b = 0, float *copy_a = nullptr,
-               float *copy_b = nullptr, int acc_copy = 0)
+               float *copy_b = nullptr, int acc_copy = 0, const float *w2 = nullptr)
 {
     int R = (N + 63) / 64;
     if (R > COLRED_MAXR) R = COLRED_MAXR;
     if (R < 1) R = 1;
     const int rows = (N + R - 1) / R;
     const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var, acc_a, acc_b, copy_a, copy_b, acc_copy};
-    hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part);
+    hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part, w2);
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f);
 }
 
@@ -1227,8 +1232,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         default: hipLaunchKernelGGL(att_bwd_source_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, st, Bk); break;
         }
         // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
-        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, nullptr, nullptr, nullptr, acc);
-        colreduce(st, G, F(w.da_dst), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_dst, nullptr, nullptr, nullptr, acc);
+        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, Gl.att_dst, nullptr, nullptr, acc,
+                  acc, nullptr, nullptr, 0, F(w.da_dst));
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
             if (use_edge) {
                 hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,

@@ -186,6 +186,27 @@ def test_coresident_other_dims():
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.parametrize("dims", [(16, 16, 1), (48, 32, 5), (64, 128, 67), (800, 256, 800), (32, 1024, 33)])
+def test_odd_dimensions_all_kernel_sets(dims):
+    """Feature sizes off the tiles' grain (K of 16 / 48 / 64, output widths 1, 5, 33, 67 -- scalar epilogue, clamped column
+    loads, the residual_proj second GEMM; hidden 1024 = 16 k-chunks and 4 float4 chunks per aggregate lane): the four kernel
+    sets agree bit for bit and sit within the oracle bar."""
+    i, h, o = dims
+    m = _model(edge_dim=2, hidden_dim=h, input_dim=i, output_dim=o)
+    n = 131
+    g = gm.synthetic_chain_graph(n, device="cuda", seed=i + o)
+    g.x = torch.rand((n, i), device="cuda")
+    outs = []
+    with torch.no_grad():
+        for ks in (False, True, "shared_b", "lds_tiled"):
+            m.gnn.coresident = ks
+            outs.append(m(g))
+        m.gnn.coresident = False
+    for t in outs[1:]:
+        assert torch.equal(outs[0], t)
+    _check(outs[0], m, g)
+
+
 def test_pipelined_path_matches_serial():
     """ShardedDescriptorPath(pipeline=True): encoder of batch k+1 on one stream over the GNN of batch k on a
     second one, double-buffered descriptors -- every step's results equal the one-stream path's."""

@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--gnn-streams", type=int, default=1, help=argparse.SUPPRESS)    # GNN passes alternate over this many streams
     ap.add_argument("--gnn-graph", type=int, default=-1, help=argparse.SUPPRESS)     # GNN forward as a replayed hipGraph: 1 / 0, -1 = the path's default
     ap.add_argument("--gnn-nodes", type=int, default=0, help=argparse.SUPPRESS)      # DIAGNOSTIC: GNN over the first n keyframes only
+    ap.add_argument("--gnn-burn", default="", help=argparse.SUPPRESS)                # DIAGNOSTIC: MODE:WGS:PER_WAVE[:LAUNCHES] synthetic co-runner (nsc_debug_burn) in place of the GNN
     ap.add_argument("--no-gnn", action="store_true", help=argparse.SUPPRESS)         # DIAGNOSTIC (not the metric): identity in place of the GNN
     args = ap.parse_args()
 
@@ -328,6 +329,20 @@ def main():
         def __call__(self, g):
             return g.x
 
+    class _BurnGnn:                                         # --gnn-burn MODE:WGS:PER_WAVE[:LAUNCHES]: a synthetic co-runner of ONE resource
+        def __init__(self, spec):
+            from neural_spectral_codec_amd import _lib as L_
+            f = [int(v) for v in spec.split(":")]
+            self.mode, self.wgs, self.per_wave, self.launches = f[0], f[1], f[2], (f[3] if len(f) > 3 else 1)
+            self.L, self.lib = L_, L_.lib()
+            self.scratch = torch.rand(1 << 19, dtype=torch.float32, device=dev)          # 2 MB
+
+        def __call__(self, g):
+            for _ in range(self.launches):
+                self.L.check(self.lib.nsc_debug_burn(self.mode, self.wgs, self.per_wave, self.L.ptr(self.scratch),
+                                                     self.scratch.numel() * 4, self.L.stream_ptr(dev)), "nsc_debug_burn")
+            return g.x
+
     class _PartGnn:                                         # --gnn-nodes n: is the GNN's cost beside the encoder work- or launch-bound?
         def __init__(self, n):
             from neural_spectral_codec_amd.keyframe import graph_manager as gm_
@@ -340,7 +355,8 @@ def main():
             return out
 
     def make_path(pipelined, enc_streams=1):
-        gnn_ = _NoGnn() if args.no_gnn else (_PartGnn(args.gnn_nodes) if args.gnn_nodes else model)
+        gnn_ = (_BurnGnn(args.gnn_burn) if args.gnn_burn else _NoGnn() if args.no_gnn
+                else (_PartGnn(args.gnn_nodes) if args.gnn_nodes else model))
         p_ = nd.ShardedDescriptorPath(enc, gnn_, n_total, poses, pipeline=pipelined,
                                       encoder_streams=enc_streams,
                                       gnn_streams=args.gnn_streams, gnn_graph=None if args.gnn_graph < 0 else bool(args.gnn_graph))
@@ -515,7 +531,7 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
-            "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds" + (" -- DIAGNOSTIC RUN WITHOUT THE FULL GNN, not the metric" if (args.no_gnn or args.gnn_nodes) else ""),
+            "metric": "keyframes/sec (encode+GAT fwd), 120k-pt clouds" + (" -- DIAGNOSTIC RUN WITHOUT THE FULL GNN, not the metric" if (args.no_gnn or args.gnn_nodes or args.gnn_burn) else ""),
             "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,

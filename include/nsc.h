@@ -225,6 +225,13 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
 #define NSC_GAT_LDS_TILED 4u
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream);
+/* Diagnostic co-runner (bench.py --gnn-burn): `workgroups` x 4 waves of the co-resident GNN kernels' footprint (0 B of LDS,
+ * < 56 VGPRs), each wave issuing `per_wave` operations of ONE kind -- mode 0: v_mfma_f32_16x16x4_f32 on register operands
+ * (4 independent accumulators), 1: v_fma_f32 (64 lanes), 2: 16-byte loads from a 1 MB L2-resident buffer (`scratch`, >= 1 MB),
+ * 3: ds_bpermute_b32, 4: 16-byte loads that hit L1 (every wave the same 16 KB), 5: 16-byte loads of which the four waves of a
+ * workgroup read the same addresses.  Answers what a given amount of one resource costs the kernel it runs beside.  scratch also takes the
+ * (never read) results. */
+int nsc_debug_burn(int32_t mode, int32_t workgroups, int32_t per_wave, float *scratch, size_t scratch_bytes, void *stream);
 /* Which tile the default (LDS-DMA) GEMM takes for C[M,N] = A[M,K] B[N,K]^T -- host function, no device work: rows and
  * columns of a workgroup tile, its LDS bytes and the number of workgroups (a grid of at most 256 is one round on the
  * 256 CUs).  Returns NSC_OK, or NSC_EINVAL for non-positive sizes / K not a multiple of 16. */

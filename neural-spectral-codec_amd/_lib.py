@@ -111,6 +111,7 @@ SYMBOLS = {
     "nsc_gat_forward_ex": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, _vp, _vp, _vp, _sz, C.c_uint32,
                                      _vp]),
     "nsc_gat_gemm_tile": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "nsc_debug_burn": (C.c_int, [_i32, _i32, _i32, _vp, _sz, _vp]),
     "nsc_graph_transpose_workspace_bytes": (_sz, [_i32]),
     "nsc_graph_transpose": (C.c_int, [C.POINTER(Graph), _vp, _vp, _vp, _vp, _sz, _vp]),
     "nsc_gat_train_workspace_bytes": (_sz, [C.POINTER(GatModel), C.POINTER(Graph)]),

@@ -802,6 +802,50 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
     }
 }
 
+// Diagnostic co-runner (nsc_debug_burn): one kind of operation per launch, in the co-resident kernels' footprint.
+__global__ __launch_bounds__(256) void burn_kernel(int mode, int per_wave, float *__restrict__ scratch)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f}, {0.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f}};
+    float a = 1.0f + (float)lane * 1e-3f, b = 0.5f + (float)(gid & 7) * 1e-3f, v = a;
+    asm volatile("" : "+v"(a), "+v"(b));
+    if (mode == 0) {
+        for (int i = 0; i < per_wave; i += 4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+        }
+    } else if (mode == 1) {
+        float x0 = a, x1 = b, x2 = a + b, x3 = a - b;
+        for (int i = 0; i < per_wave; i += 4) {
+            x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+        }
+        v = (x0 + x1) + (x2 + x3);
+    } else if (mode == 2 || mode == 4 || mode == 5) {
+        // 2: 1 MB = 65 536 quads, every wave walks all of it from its own start (L2 hits); 4: every wave of the chip walks the
+        // same 16 KB (L1 hits); 5: the four waves of a workgroup read the same addresses of the 1 MB (one L2 fetch, three L1 hits)
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(scratch);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        const unsigned mask = mode == 4 ? 1023u : 65535u;
+        unsigned idx = mode == 4 ? 0u : mode == 5 ? (blockIdx.x * 256u * 64u) & 65535u : (gid * 64u) & 65535u;
+        for (int i = 0; i < per_wave; i += 4) {
+            f32x4 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c] = src[(idx + 64u * c + lane) & mask];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s += t[c];
+            idx += 256u;
+        }
+        v = (s.x + s.y) + (s.z + s.w);
+    } else {
+        int x = __float_as_int(a);
+        for (int i = 0; i < per_wave; ++i) x = __builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, x);
+        v = __int_as_float(x);
+    }
+    if (mode == 0) v = (acc[0].x + acc[1].y) + (acc[2].z + acc[3].w);
+    if (v == 12345.678f) scratch[(1u << 18) + (gid & 1023u)] = v;          // keeps the work alive; practically never true
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1002,6 +1046,14 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
                     float *out, float *alpha_out, void *ws, size_t ws_bytes, void *stream_)
 {
     return nsc_gat_forward_ex(m, g, x, edge_attr, out, alpha_out, ws, ws_bytes, 0u, stream_);
+}
+
+int nsc_debug_burn(int32_t mode, int32_t workgroups, int32_t per_wave, float *scratch, size_t scratch_bytes, void *stream_)
+{
+    if (mode < 0 || mode > 5 || workgroups < 0 || per_wave < 0 || !scratch || scratch_bytes < (1u << 20)) return NSC_EINVAL;
+    if (workgroups == 0) return NSC_OK;
+    hipLaunchKernelGGL(burn_kernel, dim3((unsigned)workgroups), dim3(256), 0, static_cast<hipStream_t>(stream_), mode, per_wave, scratch);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 
 int nsc_gat_gemm_tile(int32_t M, int32_t N, int32_t K, int32_t *tile_rows, int32_t *tile_cols, int32_t *lds_bytes,

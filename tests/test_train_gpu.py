@@ -112,6 +112,52 @@ def test_forward_train_and_gradients(n, edge_dim):
     assert int(m.gnn.input_norm.num_batches_tracked) == 1
 
 
+def test_gradients_on_hub_graph():
+    """The attention kernels of the training step take a fast path for in-degree <= 64 (one entry per lane, float4 gathers)
+    and a general loop above it; the per-source pass walks lists of any length in chunks of 64.  A graph with a hub that
+    150 nodes point to and that points to 150 others (plus a chain, duplicate edges and explicit self loops) runs both;
+    embedding, loss, every gradient and the input gradient against autograd through the restatement."""
+    from types import SimpleNamespace
+    n = 400
+    torch.manual_seed(3)
+    m = create_spectral_gnn(edge_dim=2, dropout=0.0)
+    go.randomize_bn_stats(m, 4)
+    m = m.to("cuda")
+    rng = np.random.default_rng(5)
+    i = np.arange(n - 1)
+    hub = 7
+    src = np.concatenate([i, i + 1, np.arange(20, 170), np.full(150, hub), rng.integers(0, n, 60), np.arange(0, n, 9)])
+    dst = np.concatenate([i + 1, i, np.full(150, hub), np.arange(200, 350), rng.integers(0, n, 60), np.arange(0, n, 9)])
+    src = np.concatenate([src, src[:40]]); dst = np.concatenate([dst, dst[:40]])         # duplicate edges
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64))
+    x = torch.rand((n, 800)) ** 4
+    x = x / x.sum(1, keepdim=True)
+    ea = torch.rand((ei.shape[1], 2))
+    g = SimpleNamespace(x=x.cuda(), edge_index=ei.cuda(), edge_attr=ea.cuda(), num_nodes=n)
+    trip = np.stack([rng.integers(0, n, 256), rng.integers(0, n, 256), rng.integers(0, n, 256)], 1)
+    tt = torch.from_numpy(trip)
+    R = torch.randn(n, 800, generator=torch.Generator().manual_seed(9)) * 1e-3
+    emb_ref, grads_ref, gx_ref, loss_ref = go.reference_gradients(
+        m, g, lambda e: go.triplet_loss_reference(e, tt[:, 0], tt[:, 1], tt[:, 2], 0.1) + (e * R).sum())
+    m.train()
+    g.x.requires_grad_(True)
+    emb = m(g)
+    loss = TripletLoss(margin=0.1).forward_indexed(emb, trip[:, 0], trip[:, 1], trip[:, 2]) + (emb * R.cuda()).sum()
+    loss.backward()
+    emb64 = go.reference_gradients(m, g, lambda e: (e * 0).sum(), dtype=torch.float64)[0]
+    _assert_train_forward(emb, emb_ref, emb64, "train-mode forward, hub graph")
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 1e-6
+    params = dict(m.gnn.named_parameters())
+    gscale = max(v.abs().max().item() for v in grads_ref.values())
+    for k in _key_map(m.gnn):
+        got = params[k].grad.detach().cpu().reshape(grads_ref[k].shape)
+        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
+            assert got.abs().max().item() < 1e-3 * gscale and grads_ref[k].abs().max().item() < 1e-3 * gscale, k
+            continue
+        assert _rel(got, grads_ref[k]) < 2e-3, k
+    assert _rel(g.x.grad.cpu(), gx_ref) < 2e-3
+
+
 @pytest.mark.parametrize("in_dim,out_dim,residual", [(800, 800, False), (64, 32, False), (32, 64, False),
                                                      (64, 48, True), (48, 80, True)])
 def test_residual_variants_train(in_dim, out_dim, residual):

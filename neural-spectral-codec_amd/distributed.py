@@ -381,11 +381,12 @@ class ShardedDescriptorPath:
         3).  A capture is keyed on the input's storage and the model's parameter versions: new weights or a new input
         buffer recapture; an input that is not one of the rotating buffers (ragged shards) runs eagerly."""
         x = self._graph.x
+        inner = getattr(self.gnn, "gnn", self.gnn)
         if not (self.gnn_graph and self.pipeline and x.is_cuda and not torch.is_grad_enabled()
-                and not getattr(self.gnn, "training", False)):
+                and not getattr(self.gnn, "training", False)
+                and (hasattr(inner, "_live_tensors") or hasattr(inner, "parameters"))):     # (a plain callable runs eagerly)
             return self.gnn(self._graph)
         slot = self._k % self._PIPE_BUFFERS
-        inner = getattr(self.gnn, "gnn", self.gnn)
         key = (x.data_ptr(), tuple(x.shape),
                tuple((t.data_ptr(), t._version) for t in (inner._live_tensors() if hasattr(inner, "_live_tensors")
                                                           else list(inner.parameters()) + list(inner.buffers()))),

@@ -392,14 +392,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 // forward of batch k can then run on a second stream under the encoder of batch k+1.  Same k order and
 // operand assignment as gemm_nt_kernel, so the results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <int ACC, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__restrict__ A, int lda,
+template <int ACC, int EPI, int P = 4>     // P: k-blocks in the register ring
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) void gemm_nt_direct_kernel(const float *__restrict__ A, int lda,
                                                              const float *__restrict__ B, int ldb,
                                                              const float *__restrict__ Bx, int M, int N,
                                                              int n_main, int K, float *__restrict__ C, int ldc,
                                                              GemmEpi ep)
 {
-    constexpr int BM = 16 * ACC, P = 4;
+    constexpr int BM = 16 * ACC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -435,13 +435,6 @@ __global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__rest
         return o;
     };
 
-    float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
-    if (EPI != 0) bias = ep.bias[col];
-    if (EPI == 1) {
-        const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
-        bn_scale = invstd * ep.bn_w[col];
-        bn_shift = ep.bn_b[col] - ep.bn_mean[col] * bn_scale;
-    }
 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[ACC];
@@ -478,6 +471,15 @@ __global__ __launch_bounds__(256) void gemm_nt_direct_kernel(const float *__rest
     }
 
     if (cb >= N) return;
+    // (epilogue operands fetched here, not ahead of the loop: three registers less through it -- the 32-row form has to fit
+    // 56 VGPRs for two of its waves to share a SIMD with five encoder workgroups; their round trip hides under other waves)
+    float bias = 0.f, bn_scale = 1.f, bn_shift = 0.f;
+    if (EPI != 0) bias = ep.bias[col];
+    if (EPI == 1) {
+        const float invstd = 1.0f / sqrtf(ep.bn_var[col] + ep.bn_eps);
+        bn_scale = invstd * ep.bn_w[col];
+        bn_shift = ep.bn_b[col] - ep.bn_mean[col] * bn_scale;
+    }
     const bool main_col = cb < n_main;
 #pragma unroll
     for (int h = 0; h < ACC; ++h) {
@@ -951,10 +953,18 @@ void launch_gemm(hipStream_t st, int cores, const float *A, int lda, const float
 #define ep epd
 #endif
     if (coresident) {
-        // one accumulator row block: 48 VGPRs.  Larger tiles (fewer B re-reads) were measured to disturb the
-        // co-running encoder MORE (longer uninterrupted MFMA bursts), DESIGN.md section 7.
-        hipLaunchKernelGGL((gemm_nt_direct_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N,
-                           n_main, K, C, ldc, ep);
+        // Round 3: 32-row tiles (two accumulators share every B operand) with a 2-deep register ring -- 54 VGPRs, so two of
+        // its waves still share a SIMD with five encoder workgroups.  Beside an HBM-saturating kernel a co-runner pays for
+        // the bytes it fetches from beyond L1 (experiment 17e): the weight block is fetched once per 32
+        // rows instead of once per 16.  Step 303.9 -> 299.9 us (3 of 3 interleaved pairs); round 2's 32-row form had a 4-deep
+        // ring and 68+ VGPRs (one wave per SIMD) and measured slower.  A single 16-row tile keeps the 16-row form.
+        if (M > 16) {
+            const dim3 g2((N + 63) / 64, (M + 31) / 32);
+            hipLaunchKernelGGL((gemm_nt_direct_kernel<2, EPI, 2>), g2, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N, n_main, K, C, ldc, ep);
+        } else {
+            hipLaunchKernelGGL((gemm_nt_direct_kernel<1, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, Bx, M, N,
+                               n_main, K, C, ldc, ep);
+        }
     } else if (four) {
         hipLaunchKernelGGL((gemm_nt_kernel<2, EPI, 2>), grid, dim3(256), lds, st, A, lda, B, ldb, Bx, M, N, n_main,
                            K, C, ldc, ep);

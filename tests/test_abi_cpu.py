@@ -84,6 +84,8 @@ def test_argument_validation_without_gpu(lib):
     p.n_elevation = 16
     # the rows added around the path: shape checks answer without a device as well
     assert lib.nsc_gat_forward_ex(None, None, None, None, None, None, None, 0, 2, None) == -1     # unknown flag
+    assert lib.nsc_gat_forward_ex(None, None, None, None, None, None, None, 0, 5, None) == -1     # LDS_TILED excludes CORESIDENT
+    assert lib.nsc_debug_burn(9, 1, 1, None, 0, None) == -1 and lib.nsc_debug_burn(0, 1, 1, None, 1 << 20, None) == -1
     assert lib.nsc_quantize_descriptors(None, 0, 800, 1e-8, None, None) == 0
     assert lib.nsc_quantize_descriptors(None, 3, 800, 1e-8, None, None) == -1
     assert lib.nsc_quantize_descriptors(None, 3, 5000, 1e-8, None, None) in (-1, -2)

@@ -10,7 +10,9 @@ One "step" = one pass of the hot path over one batch of synthetic input PER RANK
       -> 3-layer GAT forward over the rank's keyframe range + 6-node halo (nsc_gat_forward)
 Work per GPU is fixed as N grows (weak scaling); value = N * 1 024 * K / max-over-ranks time.
 
-For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU).
+For N > 1 either launch this file under torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment), or call it directly: without WORLD_SIZE in the environment ``python bench.py --gpus N``
+starts its own N ranks as fresh child processes (self_launch) and relays rank 0's line.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -24,6 +26,74 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "oracle")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
+
+
+def self_launch(n_gpus: int) -> int:
+    """``python bench.py --gpus N`` called directly (no WORLD_SIZE in the environment) for N > 1: this process becomes a
+    launcher that never touches the GPU (it imports neither torch nor anything of the package) -- it starts N fresh child
+    processes of this file, one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
+    ``python -m torch.distributed.run`` would set them, relays rank 0's stdout (the ONE JSON line), sends the other ranks'
+    stdout to stderr, and returns non-zero when any child does.  No exec: the children are ordinary subprocesses, and when
+    one fails the others are ended by their exact PIDs."""
+    import socket
+    import subprocess
+    import threading
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    base = dict(os.environ, WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=port, NSC_BENCH_SELF_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL's dmabuf IPC (the host driver has no legacy IPC)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+
+    def relay():
+        for raw in procs[0].stdout:
+            sys.stdout.write(raw.decode("utf-8", "replace"))
+            sys.stdout.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc, failed_at = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and failed_at is None:
+            rc, failed_at = bad[0], time.time()
+            print(f"[bench launcher] a rank exited with status {rc}; ending the others", file=sys.stderr)
+        if all(c is not None for c in codes):
+            break
+        if failed_at is not None:
+            # the survivors are most likely parked in a collective waiting for the dead rank: give them a moment, then
+            # end exactly the processes started above
+            age = time.time() - failed_at
+            for p in procs:
+                if p.poll() is None:
+                    if age > 20:
+                        p.kill()
+                    elif age > 5:
+                        p.terminate()
+        time.sleep(0.2)
+    th.join(timeout=5)
+    return rc if rc else max((abs(p.returncode) for p in procs), default=0)
+
+
+def _early_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _early_gpus(sys.argv[1:]) > 1:
+    sys.exit(self_launch(_early_gpus(sys.argv[1:])))       # before torch is imported: the launcher stays off the GPU
 
 import numpy as np
 import torch
@@ -231,7 +301,130 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
         orders = {k: float(np.median(v)) for k, v in times.items()}
         del sets
         out["encoder_input_order_ms"] = orders
+        try:
+            out["incl_h2d"] = measure_h2d(enc, model, dev, n_local, uniform)
+            out["latency_us"] = measure_latencies(enc, model, dev)
+        except Exception as ex:  # noqa: BLE001 -- side measurements must not take the bench down
+            print(f"[bench] H2D / latency extras not measured ({type(ex).__name__}: {ex})", file=sys.stderr)
     gc.enable()
+    return out
+
+
+def measure_h2d(enc, model, dev, n_local, uniform):
+    """SURVEY 8(d)'s second number: the same step when the boundary hands over HOST buffers -- the batch starts in pinned
+    host memory every step; the copy of batch k+1 (second stream) overlaps encoder + GAT of batch k.  PCIe-bound: never
+    `value`.  The reference pays a per-keyframe H2D at src/encoding/spectral_encoder.py:224."""
+    from neural_spectral_codec_amd.keyframe import graph_manager as gm
+    pts, off = uniform
+    host = torch.empty(pts.shape, dtype=torch.float32, pin_memory=True)
+    host.copy_(pts)
+    bufs = [torch.empty_like(pts) for _ in range(2)]
+    desc = torch.empty((n_local, 800), dtype=torch.float32, device=dev)
+    g = gm.synthetic_chain_graph(n_local, device=dev, seed=1)
+    g.x = desc
+    copy_s = torch.cuda.Stream(device=dev)
+    evs = [torch.cuda.Event() for _ in range(2)]
+    cur = torch.cuda.current_stream(dev)
+
+    def run(steps):
+        for k in range(steps):
+            i = k & 1
+            with torch.cuda.stream(copy_s):
+                bufs[i].copy_(host, non_blocking=True)
+                evs[i].record(copy_s)
+            cur.wait_event(evs[i])
+            enc.encode_points_batch((bufs[i], off), out=desc)
+            model(g)
+            copy_s.wait_stream(cur)                          # buffer i is free again two steps later
+        torch.cuda.synchronize(dev)
+
+    run(3)
+    steps = 8
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    del bufs, host
+    return {"value": n_local / dt, "unit": "keyframes/s", "ms_per_step": dt * 1e3,
+            "pcie_GBps": pts.numel() * 4 / dt / 1e9, "steps": steps,
+            "what": f"the {n_local} x {N_POINTS}-point batch starts in PINNED HOST memory every step: H2D copy (second stream, "
+                    "batch k+1 under the compute of batch k) + encoder + GAT forward; PCIe-bound, not `value`"}
+
+
+def measure_latencies(enc, model, dev):
+    """Per-call latency of the REFERENCE-SHAPED call sequence (src/pipeline.py:245-274: one encode_points + one
+    sliding-window gnn(graph) per keyframe, add_keyframe + stage-1 query against the database; the reference's stated
+    targets are latencies, configs/training.yaml:98-99: encoding < 10 ms, query 27 ms @ 100 K database).  Host wall clock
+    per call, each call synchronous the way the reference's callers make it (they read the result on the host)."""
+    from types import SimpleNamespace
+    from neural_spectral_codec_amd import synth
+    from neural_spectral_codec_amd.keyframe import graph_manager as gm
+    from neural_spectral_codec_amd.retrieval.two_stage_retrieval import TwoStageRetrieval
+
+    def timed(fn, reps, warm=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    out = {}
+    cloud = synth.make_cloud(0, N_POINTS)
+    # pipeline.py:245  descriptor = self.encoder.encode_points(points).detach().cpu().numpy()
+    out["encode_points_numpy_120k_incl_h2d_d2h"] = timed(lambda: enc.encode_points(cloud).detach().cpu().numpy(), 100)
+    dcloud = torch.from_numpy(cloud).to(dev)
+    out["encode_points_device_resident"] = timed(lambda: enc.encode_points(dcloud), 100)
+    # pipeline.py:250-256  graph_manager.add_keyframe(kf); graph = get_graph(); embeddings = gnn(graph); update_embeddings
+    window = 1000
+    mgr = gm.TemporalGraphManager(temporal_neighbors=5, max_active_nodes=window, feature_dim=800, device=str(dev))
+    rng = np.random.default_rng(5)
+    descs = rng.random((window + 64, 800), dtype=np.float32)
+    descs /= descs.sum(1, keepdims=True)
+    kid = [0]
+
+    def add_kf():
+        kf = SimpleNamespace(keyframe_id=kid[0], descriptor=descs[kid[0] % len(descs)], embedding=None)
+        kid[0] += 1
+        mgr.add_keyframe(kf)
+        return kf
+
+    for _ in range(window):
+        add_kf()
+
+    def online_step():
+        add_kf()
+        emb = model(mgr.get_graph())
+        return emb[-1].cpu()                                  # the caller reads the new keyframe's embedding
+
+    out["add_keyframe_plus_gnn_1000_node_window"] = timed(online_step, 60)
+    g = mgr.get_graph()
+    out["gnn_graph_1000_node_window_synchronous"] = timed(lambda: (model(g), torch.cuda.synchronize(dev)), 100)
+    out["gnn_graph_1000_node_window_async_issue"] = timed(lambda: model(g), 100)
+    # pipeline.py:259-266  retrieval_system.add_keyframe(kf); get_loop_closures(kf) -- stage 1 on a 100 K database
+    n_db = 100000
+    ts = TwoStageRetrieval(top_k=10, spatial_filter_distance=50.0, device=str(dev))
+    db = torch.rand((n_db, 800), dtype=torch.float32, device=dev) ** 3
+    pos = torch.rand((n_db, 3), dtype=torch.float32, device=dev) * 2000.0
+    ts.retriever.add_to_database(db, positions=pos)
+    ts.keyframes.extend([None] * n_db)                        # stage 1 only needs the count (stage 2 reads the objects)
+    pose = np.eye(4)
+    q = [0]
+
+    def retrieval_step():
+        pose_k = pose.copy()
+        pose_k[:3, 3] = (1000.0 + q[0], 1000.0, 0.0)
+        kf = SimpleNamespace(keyframe_id=n_db + q[0], descriptor=descs[q[0] % len(descs)], pose=pose_k, points=None)
+        q[0] += 1
+        ts.add_keyframe(kf)
+        return ts.query(kf, verify=False)
+
+    out["add_keyframe_plus_stage1_query_100k_db"] = timed(retrieval_step, 40)
+    out["targets_of_the_reference_us"] = {"encoding_time": 10000, "query_latency_100k_db": 27000}
+    out["what"] = ("host wall clock per call of the reference-shaped sequence (src/pipeline.py:245-274), synchronous "
+                   "where the reference's caller reads the result; targets: configs/training.yaml:98-99")
+    del ts, db, pos
     return out
 
 
@@ -266,8 +459,10 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        # (python bench.py --gpus N without WORLD_SIZE never gets here: self_launch() above starts the N ranks)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1: unset WORLD_SIZE to let bench.py start its own ranks, or "
+                         "launch with python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     # NSC_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a ONE-GPU box (all ranks share cuda:0,
     # collectives over gloo).  Never used for reported numbers.
     rehearsal = os.environ.get("NSC_BENCH_REHEARSAL") == "1"
@@ -280,6 +475,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    # self-description of the N > 1 line: how many ranks the communicator really joined (an all-reduce of ones), on what
+    rccl_ranks, backend = 1, None
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks, backend = int(round(float(ones.item()))), str(dist.get_backend())
 
     from neural_spectral_codec_amd import synth
     from neural_spectral_codec_amd import distributed as nd
@@ -449,7 +650,7 @@ def main():
             calib["steps_each"] = 2 * CALIB_STEPS
             calib["rounds_ms_per_step_rank0"] = calib_all
             best = names[int(torch.argmin(tcal))]
-            if best != "serial":
+            if best != "serial" and os.environ.get("NSC_BENCH_KEEP_PATH") != "1":     # (diagnostic: keep the calibrated object)
                 # The timed region runs on a FRESH path object (new streams), spun up after the calibration.  Round 3: the
                 # first multi-path process on a fresh box ran its timed region 8-10 % slower on the path object it had
                 # calibrated (7 of 7 boxes; the same path calibrated fast, launches overlapped, distinct hardware queues);
@@ -465,6 +666,11 @@ def main():
         chosen = [n_ for n_, p_ in paths.items() if p_ is path][0]
         for _ in range(args.warmup):                        # the W untimed warmup steps of the contract
             path.step(next_batch(), inputs_ready=True)
+        if world > 1:
+            # HIP events around the descriptor all-gather, on the stream it is issued on (every step's; allocated here,
+            # outside the timed region)
+            path.collective_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                      for _ in range(args.steps)]
         sync()                                              # barrier + synchronize: microseconds of idle, no more
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -504,16 +710,41 @@ def main():
         if rank == 0 and world == 1 and not args.no_extras:
             extras = measure_extras(enc, model, dev, n_local, scratch, (pts, off))
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank_ms, allgather = None, None
     if world > 1:
+        tl = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(tl, t)
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in tl.tolist()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # the descriptor all-gather: in situ (events of the timed region: from the moment the GNN stream reaches the
+        # collective to its completion, beside the resident encoder grid) and alone on an idle device afterwards
+        ce = [a.elapsed_time(b) for a, b in (path.collective_events or []) if a.query() and b.query()]
+        ga = torch.empty((n_total, 800), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(ga, desc_local.contiguous())
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            dist.all_gather_into_tensor(ga, desc_local.contiguous())
+        b.record()
+        torch.cuda.synchronize(dev)
+        alone_ms = a.elapsed_time(b) / 20
+        allgather = {"in_situ_ms": float(np.mean(ce)) if ce else None, "in_situ_max_ms": float(np.max(ce)) if ce else None,
+                     "events": len(ce), "alone_ms": alone_ms, "bytes_per_rank": n_local * 3200,
+                     "alone_bus_GBps": (world - 1) * n_local * 3200 / (alone_ms * 1e-3) / 1e9}
+        del ga
     dt = float(t.item())
     enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[::args.ev_every]]))
     # launch period in the timed region: completion to completion.  Steady state: the first RAMP launches after the
     # synchronise before t0 are left out (the first launch runs alone, the second starts a host-issue time later: their
     # completions are 340-370 us apart, the steady state's 300-310); the whole region's figure is reported beside it.
+    # ... and the LAST interval too (round 4): the final launch drains without a successor streaming beside it, its
+    # completion comes early (251 us against 300 in the round-3 driver run) and would flatter the in-situ figure.
     RAMP = 4 if args.steps >= 12 else 0
+    DRAIN = 1 if args.steps >= 12 else 0
     period_all_ms = ev[0][1].elapsed_time(ev[-1][1]) / (args.steps - 1) if args.steps > 1 else enc_ms
-    period_ms = (ev[RAMP][1].elapsed_time(ev[-1][1]) / (args.steps - 1 - RAMP)) if args.steps - 1 - RAMP > 0 else period_all_ms
+    nper = args.steps - 1 - RAMP - DRAIN
+    period_ms = (ev[RAMP][1].elapsed_time(ev[-1 - DRAIN][1]) / nper) if nper > 0 else period_all_ms
     overlapped = chosen == "pipelined2"
 
     if rank == 0:
@@ -544,6 +775,9 @@ def main():
                              "launch_windows_us": ([(round(ev[0][0].elapsed_time(ev[k][0]) * 1e3, 1),
                                                      round(ev[0][0].elapsed_time(ev[k][1]) * 1e3, 1))
                                                     for k in range(min(args.steps, 64))] if args.ev_every == 1 else None)},
+            "rccl_ranks": rccl_ranks, "backend": backend, "ms_per_step_by_rank": per_rank_ms, "allgather": allgather,
+            "launched_by": ("bench.py itself (N fresh child processes)" if os.environ.get("NSC_BENCH_SELF_LAUNCHED") == "1"
+                            else "torch.distributed.run / caller" if world > 1 else "single process"),
             "step_path": "serial" if chosen == "serial" else "pipelined",
             "encoder_streams": {"pipelined2": 2, "pipelined1": 1}.get(chosen, 1), "calibration": calib,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -563,8 +797,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "achieved_defined_on": ("launch period: algorithmic bytes of one launch / time between consecutive launch "
                                         "completions in the steady state of the timed region (its first %d launches, the "
-                                        "pipeline's ramp after the synchronise before t0, left out; consecutive launches "
-                                        "overlap on two streams, two are resident at a time)" % RAMP if overlapped else
+                                        "pipeline's ramp after the synchronise before t0, and its last %d, which drains "
+                                        "without a successor, left out; consecutive launches "
+                                        "overlap on two streams, two are resident at a time)" % (RAMP, DRAIN) if overlapped else
                                         "launch duration: algorithmic bytes of one launch / HIP-event time around the launch"),
                 "traffic": traffic,
                 "traffic_source": "profiles/encoder_traffic.json (PMC FETCH_SIZE + WRITE_SIZE, separate rocprofv3 run; not a same-run counter)",
@@ -580,6 +815,11 @@ def main():
         }
         if extras:
             line["roofline_gat"] = extras["roofline_gat"]
+            if "incl_h2d" in extras:
+                line["value_incl_h2d"] = extras["incl_h2d"]["value"]
+                line["incl_h2d"] = extras["incl_h2d"]
+            if "latency_us" in extras:
+                line["latency_us"] = extras["latency_us"]
             # the headline workload is the uniform-order batch; the same kernel alone on sensor-ordered clouds:
             line["roofline"]["standalone_launch_ms_by_input_order"] = dict(extras["encoder_input_order_ms"])
         if world == 1 and not args.no_cpu_baseline:

@@ -193,6 +193,8 @@ class ShardedDescriptorPath:
         self._streams = None
         self.queue_classes = None          # hardware-queue classes of the pipeline's streams (set with the streams)
         self.gnn_waits = 0                 # times the encoder stream had to wait for a GNN pass (buffer still being read)
+        self.collective_events = None      # optional [(start, end) HIP events]: step k times its descriptor all-gather with
+                                           # pair k % len on the stream the collective is issued on (bench.py, N > 1)
         self.last_event = None
         self.n_total, self.poses = n_total, poses
         self.M, self.L = temporal_neighbors, n_layers
@@ -327,7 +329,20 @@ class ShardedDescriptorPath:
         local = self.encoder.encode_points_batch(clouds)
         if encoder_events is not None:
             encoder_events[1].record()
-        return self._exchange_and_enhance(local)
+        res = self._exchange_and_enhance(local)
+        self._k += 1
+        return res
+
+    def _gather(self, out, local):
+        """The step's descriptor all-gather (blocking form), bracketed by the caller's HIP events when asked for."""
+        ce = self.collective_events
+        if ce and local.is_cuda:
+            a, b = ce[self._k % len(ce)]
+            a.record()
+            dist.all_gather_into_tensor(out, local, group=self.group)
+            b.record()
+        else:
+            dist.all_gather_into_tensor(out, local, group=self.group)
 
     def _exchange_and_enhance(self, local):
         if self._graph is None:
@@ -339,6 +354,9 @@ class ShardedDescriptorPath:
             d = int(local.shape[1])
             mine = torch.cat([local[:h], local[n_local - h:]], 0)
             edges_all = torch.empty((self.world * 2 * h, d), dtype=local.dtype, device=local.device)
+            ce = self.collective_events if local.is_cuda else None
+            if ce:                                   # (this form's window spans the GNN forward the big gather overlaps)
+                ce[self._k % len(ce)][0].record()
             dist.all_gather_into_tensor(edges_all, mine, group=self.group)
             # 2. the full matrix, asynchronously
             slot = 0                                 # (overlap is off in pipeline mode, see __init__)
@@ -363,7 +381,7 @@ class ShardedDescriptorPath:
                 self._desc_all[slot] = torch.empty((self.n_total, int(local.shape[1])), dtype=local.dtype,
                                                    device=local.device)
             desc_all = self._desc_all[slot]
-            dist.all_gather_into_tensor(desc_all, local.contiguous(), group=self.group)
+            self._gather(desc_all, local.contiguous())
             self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]
         else:
             desc_all = all_gather_descriptors(local, self.n_total, self.group)    # fresh tensor per step
@@ -371,6 +389,8 @@ class ShardedDescriptorPath:
         emb = self._enhance()
         if work is not None:
             work.wait()
+            if self.collective_events and local.is_cuda:
+                self.collective_events[self._k % len(self.collective_events)][1].record()
         return desc_all, emb[self._own0:self._own0 + n_local]
 
     def _enhance(self):

@@ -227,3 +227,33 @@ def test_data_parallel_train_step_through_hip_kernels(tmp_path):
     # each rank reports its weighted share (slice size / batch size) of the mean loss: the shares add up to it
     assert abs(float(one["loss"]) - (float(two[0]["loss"]) + float(two[1]["loss"]))) <= 1e-4 * abs(float(one["loss"])) + 1e-7
     assert np.allclose(one["bn_mean"], two[0]["bn_mean"], rtol=1e-6, atol=1e-7)       # replicated forward: same statistics
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with no WORLD_SIZE in the environment -- the shape of the driver's N = 1 command -- must
+    run by itself: the parent starts two fresh ranks (it never initialises HIP), relays ONE well-formed line and exits 0.
+    NSC_BENCH_REHEARSAL=1: both ranks share cuda:0 and exchange over gloo (one-GPU box)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NSC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    p = subprocess.Popen([sys.executable, bench, "--gpus", "2", "--steps", "6", "--warmup", "2", "--clouds", "96",
+                          "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path))
+    try:
+        out, err = p.communicate(timeout=900)
+    finally:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+    assert p.returncode == 0, err.decode(errors="replace")[-3000:]
+    lines = [ln for ln in out.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
+    assert line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert len(line["ms_per_step_by_rank"]) == 2 and all(v > 0 for v in line["ms_per_step_by_rank"])
+    assert line["launched_by"].startswith("bench.py itself")
+    assert line["calibration"] is not None and line["allgather"]["alone_ms"] > 0 and line["allgather"]["events"] == 6
+    assert abs(line["value"] - 2 * 96 * 6 / (line["ms_per_step"] * 6e-3)) <= 1e-6 * line["value"]
+    assert "REHEARSAL" in line["data"]

@@ -244,3 +244,20 @@ def test_stream_loop_isa(lib, tmp_path):
                 assert j < len(ins), f"{name}: no wait after the load at instruction {i}"
             checked += 1
     assert checked >= 1
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """``python bench.py --gpus 2`` without WORLD_SIZE becomes a launcher that never imports torch; here (no GPU) both
+    ranks die at torch.cuda.set_device and the launcher must end with a non-zero status instead of hanging or exec-ing."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("failure path of the launcher: only meaningful without a GPU")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--clouds", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b"[bench launcher]" in p.stderr
+    assert p.stdout.strip() == b""

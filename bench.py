@@ -53,9 +53,13 @@ def self_launch(n_gpus: int) -> int:
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
 
     def relay():
+        # only rank 0's JSON line goes to stdout; anything a library prints there (gloo announces its peers on stdout)
+        # goes to stderr, so that the launcher's stdout stays ONE line
         for raw in procs[0].stdout:
-            sys.stdout.write(raw.decode("utf-8", "replace"))
-            sys.stdout.flush()
+            txt = raw.decode("utf-8", "replace")
+            dst = sys.stdout if txt.lstrip().startswith("{") else sys.stderr
+            dst.write(txt)
+            dst.flush()
 
     th = threading.Thread(target=relay, daemon=True)
     th.start()

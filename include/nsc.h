@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NSC_ABI_VERSION 3
+#define NSC_ABI_VERSION 4
 
 typedef enum NscStatus {
     NSC_OK            = 0,
@@ -185,6 +185,10 @@ typedef struct NscGraph {
     const int32_t *t_ptr;         /* (n_nodes+1) */
     const int32_t *t_entry;       /* (nnz) entry indices into src/eid, ascending per source */
     const int32_t *tgt;           /* (nnz) target node of each entry */
+    /* banded form (nsc_graph_band_entries), NULL / 0 otherwise: lets nsc_gat_forward run a GATConv layer as one launch */
+    const float   *band_entries;  /* (n_nodes, 8, 4) float32, 16-byte aligned */
+    int32_t        band;          /* half bandwidth the caller vouches for (max |source - target| <= band, and at most 8
+                                     entries per target incl. the self loop), 0 = not banded.  The kernels support <= 2 */
 } NscGraph;
 
 size_t nsc_graph_workspace_bytes(int32_t n_nodes, int64_t n_edges);
@@ -195,6 +199,17 @@ size_t nsc_graph_workspace_bytes(int32_t n_nodes, int64_t n_edges);
 int nsc_graph_build_csr(const int64_t *edge_index, int64_t n_edges, int32_t n_nodes,
                         const float *edge_attr, int32_t edge_dim, int32_t *row_ptr, int32_t *src,
                         int32_t *eid, float *loop_attr, void *ws, size_t ws_bytes, void *stream);
+
+/* Banded form of a graph whose CSR exists: per target 8 slots {source (int32 bits), edge_attr[0], edge_attr[1], CSR entry
+ * index (int32 bits, -1 = empty slot)} in CSR order, self loop last with loop_attr -- the neighbourhood of a target in ONE
+ * 128-byte fetch -- plus info[0] = max |source - target| and info[1] = max entries per target over the graph (int32,
+ * device).  A caller that reads info[0] <= 2 and info[1] <= 8 sets NscGraph.band_entries / band = 2: nsc_gat_forward then
+ * runs every GATConv layer as one launch (gat_layer_banded_kernel: lin GEMM + 2-row halo, softmax, aggregation, BatchNorm
+ * in one kernel, h never leaves LDS) -- the temporal chain of the reference (src/keyframe/graph_manager.py:520-532,
+ * abs(i - j) <= 2) always qualifies.  The entries embed the edge attributes (edge_dim 0 or 2; otherwise the banded path is
+ * not taken): rebuild them when edge_attr changes.  entries: (n_nodes, 8, 4) float32, 16-byte aligned. */
+int nsc_graph_band_entries(const NscGraph *g, const float *edge_attr, int32_t edge_dim, float *entries, int32_t *info,
+                           void *stream);
 
 /* Weights-only folding, redone only when the GATConv parameters change: per layer
  * u_src = W^T att_src, u_dst = W^T att_dst (the attention dot products then ride along the lin GEMM as
@@ -223,6 +238,9 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
 #define NSC_GAT_CORESIDENT 1u
 #define NSC_GAT_SHARED_B 2u
 #define NSC_GAT_LDS_TILED 4u
+/* NSC_GAT_GENERIC: ignore NscGraph.band_entries -- every layer as lin GEMM + gat_aggregate_kernel (what irregular graphs
+ * always get).  Bit-identical to the banded path; for A/B measurements and the parity tests. */
+#define NSC_GAT_GENERIC 8u
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream);
 /* Diagnostic co-runner (bench.py --gnn-burn): `workgroups` x 4 waves of the co-resident GNN kernels' footprint (0 B of LDS,

@@ -30,7 +30,7 @@ class GatLayer(C.Structure):
         "bn_w", "bn_b", "bn_mean", "bn_var")]
 
 
-ABI_VERSION = 3            # NSC_ABI_VERSION of include/nsc.h
+ABI_VERSION = 4            # NSC_ABI_VERSION of include/nsc.h
 GAT_MAX_LAYERS = 8
 GAT_MAX_EDGE_DIM = 8
 
@@ -53,7 +53,8 @@ class Graph(C.Structure):
     """struct NscGraph"""
     _fields_ = [("n_nodes", C.c_int32), ("nnz", C.c_int32), ("row_ptr", C.c_void_p),
                 ("src", C.c_void_p), ("eid", C.c_void_p), ("loop_attr", C.c_void_p),
-                ("t_ptr", C.c_void_p), ("t_entry", C.c_void_p), ("tgt", C.c_void_p)]
+                ("t_ptr", C.c_void_p), ("t_entry", C.c_void_p), ("tgt", C.c_void_p),
+                ("band_entries", C.c_void_p), ("band", C.c_int32)]
 
 
 class GatTrainCfg(C.Structure):
@@ -104,6 +105,7 @@ SYMBOLS = {
     "nsc_debug_point_bins": (C.c_int, [_vp, _i64, _i32, _pp, _vp, _vp, _vp]),
     "nsc_graph_workspace_bytes": (_sz, [_i32, _i64]),
     "nsc_graph_build_csr": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nsc_graph_band_entries": (C.c_int, [C.POINTER(Graph), _vp, _i32, _vp, _vp, _vp]),
     "nsc_gat_folded_floats": (_sz, [C.POINTER(GatModel)]),
     "nsc_gat_fold_weights": (C.c_int, [C.POINTER(GatModel), _vp, _vp]),
     "nsc_gat_workspace_bytes": (_sz, [C.POINTER(GatModel), _i32]),

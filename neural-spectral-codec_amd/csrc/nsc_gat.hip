@@ -28,6 +28,7 @@
 namespace {
 
 #include "nsc_gemm_glds.h"
+#include "nsc_gat_banded.h"
 
 // ---------------------------------------------------------------------------------------------
 // CSR build
@@ -113,6 +114,42 @@ __global__ __launch_bounds__(256) void csr_finalize_kernel(const long long *__re
         for (int d = 0; d < NSC_GAT_MAX_EDGE_DIM; ++d)
             if (d < edge_dim) loop_attr[(long long)i * edge_dim + d] = acc[d] / cnt;
     }
+}
+
+// Banded form of the CSR (nsc_graph_band_entries): per target NSC_BAND_SLOTS 16-byte slots {source, edge_attr[0],
+// edge_attr[1], CSR entry index or -1} in CSR order -- what gat_layer_banded_kernel fetches in one round trip -- and the two
+// facts that decide whether a graph may take that kernel: info[0] = max |source - target|, info[1] = max entries per target.
+__global__ __launch_bounds__(256) void band_entries_kernel(const int *__restrict__ row_ptr, const int *__restrict__ src,
+                                                           const int *__restrict__ eid, const float *__restrict__ edge_attr,
+                                                           int edge_dim, const float *__restrict__ loop_attr, int N,
+                                                           f32x4 *__restrict__ ent, int *__restrict__ info)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int beg = row_ptr[i], end = row_ptr[i + 1];
+    int maxoff = 0;
+    for (int e = beg; e < end; ++e) {
+        const int d = src[e] - i;
+        maxoff = max(maxoff, d < 0 ? -d : d);
+    }
+#pragma unroll
+    for (int s = 0; s < NSC_BAND_SLOTS; ++s) {
+        const int e = beg + s;
+        f32x4 o = {__int_as_float(i), 0.f, 0.f, __int_as_float(-1)};
+        if (e < end) {
+            const int id = eid[e];
+            float e0 = 0.f, e1 = 0.f;
+            if (edge_attr && edge_dim > 0) {
+                const float *ea = id >= 0 ? edge_attr + (long long)id * edge_dim : loop_attr + (long long)i * edge_dim;
+                e0 = ea[0];
+                if (edge_dim > 1) e1 = ea[1];
+            }
+            o = f32x4{__int_as_float(src[e]), e0, e1, __int_as_float(e)};
+        }
+        ent[(long long)i * NSC_BAND_SLOTS + s] = o;
+    }
+    atomicMax(&info[0], maxoff);
+    atomicMax(&info[1], end - beg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1020,6 +1057,22 @@ int nsc_graph_build_csr(const int64_t *edge_index, int64_t E, int32_t N, const f
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 
+int nsc_graph_band_entries(const NscGraph *g, const float *edge_attr, int32_t edge_dim, float *entries, int32_t *info,
+                           void *stream_)
+{
+    if (!g || g->n_nodes < 0 || edge_dim < 0 || edge_dim > NSC_GAT_MAX_EDGE_DIM) return NSC_EINVAL;
+    if (g->n_nodes == 0) return NSC_OK;
+    if (!g->row_ptr || !g->src || !g->eid || !entries || !info) return NSC_EINVAL;
+    if (edge_attr && edge_dim > 0 && !g->loop_attr) return NSC_EINVAL;
+    if (reinterpret_cast<unsigned long long>(entries) & 15) return NSC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (hipMemsetAsync(info, 0, 2 * sizeof(int32_t), st) != hipSuccess) return NSC_ELAUNCH;
+    hipLaunchKernelGGL(band_entries_kernel, dim3((g->n_nodes + 255) / 256), dim3(256), 0, st, g->row_ptr, g->src, g->eid,
+                       (edge_dim > 0) ? edge_attr : nullptr, edge_dim, g->loop_attr, g->n_nodes,
+                       reinterpret_cast<f32x4 *>(entries), info);
+    return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+}
+
 size_t nsc_gat_folded_floats(const NscGatModel *m)
 {
     if (check_model(m) != NSC_OK) return 0;
@@ -1082,7 +1135,7 @@ int nsc_gat_gemm_tile(int32_t M, int32_t N, int32_t K, int32_t *tile_rows, int32
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream_)
 {
-    if (flags & ~(uint32_t)(NSC_GAT_CORESIDENT | NSC_GAT_SHARED_B | NSC_GAT_LDS_TILED)) return NSC_EINVAL;
+    if (flags & ~(uint32_t)(NSC_GAT_CORESIDENT | NSC_GAT_SHARED_B | NSC_GAT_LDS_TILED | NSC_GAT_GENERIC)) return NSC_EINVAL;
     if ((flags & NSC_GAT_SHARED_B) && !(flags & NSC_GAT_CORESIDENT)) return NSC_EINVAL;
     if ((flags & NSC_GAT_LDS_TILED) && (flags & NSC_GAT_CORESIDENT)) return NSC_EINVAL;
     const int cores = (flags & NSC_GAT_CORESIDENT) ? ((flags & NSC_GAT_SHARED_B) ? 2 : 1) : (flags & NSC_GAT_LDS_TILED) ? 3 : 0;
@@ -1111,10 +1164,32 @@ int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, 
     ep.relu = 1;
     launch_gemm<1>(st, cores, x, m->in_dim, m->in_w, m->in_dim, nullptr, N, H, H, m->in_dim, h0, H, ep);
 
+    // A banded graph (nsc_graph_band_entries vouches: sources within NSC_BAND_HALO rows of their target, at most
+    // NSC_BAND_SLOTS entries per target) takes ONE launch per layer; its entries carry the edge attributes, edge_dim 2 only.
+    const bool banded = !(flags & NSC_GAT_GENERIC) && cores == 0 && g->band_entries && g->band > 0 && g->band <= NSC_BAND_HALO &&
+                        (!use_edge || m->edge_dim == 2);
+
     float *cur = h0, *nxt = h1;
     for (int l = 0; l < L; ++l) {
         const NscGatLayer &Ly = m->layers[l];
         const float *auxl = aux + (size_t)l * (2 * H + NSC_GAT_MAX_EDGE_DIM);
+        if (banded) {
+            BandArgs b = {};
+            b.A = cur; b.B = Ly.lin_w; b.Bx = auxl; b.M = N; b.H = H;
+            b.ent = reinterpret_cast<const f32x4 *>(g->band_entries);
+            b.v = use_edge ? auxl + 2 * H : nullptr;
+            b.bias = Ly.bias;
+            b.bn_w = Ly.bn_w; b.bn_b = Ly.bn_b; b.bn_mean = Ly.bn_mean; b.bn_var = Ly.bn_var;
+            b.bn_eps = m->bn_eps; b.slope = m->negative_slope;
+            b.relu = (l < L - 1);
+            b.resid = (m->residual && l > 0 && l < L - 1) ? cur : nullptr;
+            b.out = nxt;
+            b.alpha_out = alpha_out ? alpha_out + (size_t)l * g->nnz : nullptr;
+            if (launch_banded_layer(st, b)) {
+                float *t = cur; cur = nxt; nxt = t;
+                continue;
+            }
+        }
         // G = cur * W^T, plus a_src = cur . u_src and a_dst = cur . u_dst as columns H, H+1
         GemmEpi e2 = {};
         e2.aux0 = a_src;

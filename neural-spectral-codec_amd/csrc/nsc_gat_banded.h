@@ -1,0 +1,350 @@
+// One GATConv layer of a BANDED graph as ONE launch (round 4): lin GEMM + attention logits + per-target softmax +
+// alpha-weighted aggregation + bias + BatchNorm(eval) (+ ReLU, + middle-layer residual).
+//   SpectralGNN.forward, layer loop        src/gnn/model.py:124-141
+//   torch_geometric 2.4.0 GATConv          src/gnn/model.py:16,75-84,127
+//   the temporal chain it runs on          src/keyframe/graph_manager.py:520-532 (abs(i - j) <= M // 2 = 2)
+//
+// The temporal graph of every reference caller is banded: a target's sources lie within HALO = 2 rows of it.  A row tile of
+// h = x W^T plus a 2-row halo either side therefore holds every neighbour row the tile's targets aggregate -- the fact
+// distributed.halo_window exploits across GPUs, used here inside one.  A workgroup owns (16 ACC - 4) target rows x 64 output
+// columns: it computes h for 16 ACC rows (the owned rows + halo) x 64 columns on gemm_glds_kernel's main loop (LDS-DMA staging
+// with source-side swizzle, three stages, one raw s_barrier per chunk, four computing + four staging waves), and the two
+// attention columns a_src = x . u_src, a_dst = x . u_dst (nsc_gat_fold_weights) for the same rows as a fifth 16-column block
+// whose row blocks are dealt over the four computing waves.  h stays in LDS: no gat_aggregate_kernel launch, no round trip of
+// h (4.65 MB written + 5 x read at 4 541 keyframes) through L2.
+//
+// Bit-identical to the generic kernel sets by construction: every h / a_src / a_dst element is the same MFMA chain (chunk
+// ascending, d = 0..3, t = 0..3, operand element t of lane (r, q) = k 64 c + 16 d + 4 q + t); the softmax reduces with the
+// same xor butterfly (a 16-lane group here, the 64-lane wave there: with at most 16 entries the upper levels of the
+// 64-lane butterfly only add zeros); the aggregation is the same fma chain in CSR entry order; the epilogue is the same
+// expression.  tests/test_gat_gpu.py compares the sets bit for bit.
+//
+// The graph comes as banded entries (nsc_graph_band_entries, built once per graph next to the CSR): 8 slots of 16 bytes per
+// target {source node, edge_attr[0], edge_attr[1], CSR entry index (-1 = empty slot)} in CSR order (self loop last, its
+// attributes = the mean of the incoming ones), so the kernel fetches a target's whole neighbourhood in ONE round trip issued
+// ahead of the main loop instead of the three dependent ones of the CSR walk (row_ptr -> src / eid -> edge_attr).
+#pragma once
+
+#define NSC_BAND_HALO 2
+#define NSC_BAND_SLOTS 8
+
+struct BandArgs {
+    const float *A;              // (M, H) layer input, row stride H
+    const float *B;              // (H, H) lin_src.weight
+    const float *Bx;             // folded [u_src H][u_dst H] (rows 0 / 1 of the attention block)
+    int M, H;
+    const f32x4 *ent;            // (M, 8) banded entries
+    const float *v;              // folded edge vector (2 floats) or null: no edge term
+    const float *bias, *bn_w, *bn_b, *bn_mean, *bn_var;
+    const float *resid;          // (M, H) or null
+    float *out;                  // (M, H)
+    float *alpha_out;            // (nnz) or null
+    float bn_eps, slope;
+    int relu;
+};
+
+__device__ __forceinline__ float group16_max(float v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int ACC, int NST = 3>
+__global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
+{
+    constexpr int HALO = NSC_BAND_HALO, SLOTS = NSC_BAND_SLOTS;
+    constexpr int BM = 16 * ACC, OWN = BM - 2 * HALO;              // rows computed / rows owned
+    constexpr int BNR = 80;                                        // B rows of a stage: 64 columns of W + the attention block
+    constexpr int ROWS = BM + BNR, NPW = ROWS / 16, STAGE = ROWS * 64;
+    constexpr int LD = 68;                                         // h tile row stride (floats)
+    constexpr int NE = (OWN * SLOTS + 255) / 256;                  // banded entries per computing thread
+    // epilogue map over the (then free) stages, in floats: h tile | a_src | a_dst | folded BatchNorm of the 64 columns | entries
+    constexpr int O_AS = BM * LD, O_AD = O_AS + BM, O_BN = O_AD + BM, O_EN = O_BN + 192;
+    static_assert(O_EN + OWN * SLOTS * 4 <= NST * STAGE, "the epilogue reuses the stages");
+    extern __shared__ __attribute__((aligned(1024))) float gemm_lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const unsigned tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int trow = (int)(tile / gridDim.x), n0 = (int)(tile % gridDim.x) * 64;
+    const int own0 = trow * OWN, rowbase = own0 - HALO;            // tile row R <-> node rowbase + R
+    const int M = a.M, K = a.H;
+    const int nchunks = K >> 6;                                    // H is a multiple of 64 (host check)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[ACC], accx[2] = {zero, zero};
+#pragma unroll
+    for (int h = 0; h < ACC; ++h) acc[h] = zero;
+    // attention row blocks of this computing wave: h = wave and h = wave + 4
+    const int nA = (wave < ACC ? 1 : 0) + (wave + 4 < ACC ? 1 : 0);
+    f32x4 pe[NE];                                                  // prefetched entries (computing waves)
+    float bn_pre[3] = {1.f, 0.f, 0.f};
+
+    if (wave8 >= 4) {
+        // ---- staging waves (as gemm_glds_kernel): piece j = tile rows 4 (wave + 4 j) .. + 3 of a 64-deep chunk
+        const float *src[NPW];
+        const int kq_base = lane & 15;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int R = 4 * (wave + 4 * j) + (lane >> 4);
+            const int kq = kq_base ^ (R & 15);
+            const float *p;
+            if (4 * (wave + 4 * j) < BM) {                          // wave-uniform: a piece is all A or all B
+                int gr = rowbase + R;                               // halo rows outside the graph re-read a valid row: no
+                gr = gr < 0 ? 0 : (gr < M ? gr : M - 1);            // target inside the graph has a source there
+                p = a.A + (long long)gr * K;
+            } else {
+                const int Rb = R - BM;
+                p = (Rb < 64) ? a.B + (long long)(n0 + Rb) * K : a.Bx + (long long)(Rb - 64 < 1 ? Rb - 64 : 1) * K;
+            }
+            src[j] = p + 4 * kq;
+        }
+        auto issue = [&](int ch, int stage) {
+            float *dst0 = gemm_lds + stage * STAGE + wave * 256;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + (ch << 6)),
+                                                 (__attribute__((address_space(3))) void *)(dst0 + j * 1024), 16, 0, 0);
+        };
+        issue(0, 0);
+        if (NST == 3 && 1 < nchunks) issue(1, 1);
+        for (int c = 0; c < nchunks; ++c) {
+            if (NST == 3 && c + 1 < nchunks) glds_wait_barrier<NPW>();
+            else glds_wait_barrier<0>();
+            if (c + NST - 1 < nchunks) issue(c + NST - 1, (c + NST - 1) % NST);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid < 256 + 64) {
+            // BatchNorm (eval) of this tile's 64 columns folded to scale / shift by the staging waves, idle from their last
+            // chunk on (gat_aggregate_kernel's expression: sc = invstd * w, shift = b - mean * sc)
+            const int col = n0 + tid - 256;
+            bn_pre[2] = a.bias[col];
+            if (a.bn_w) {
+                const float invstd = 1.0f / sqrtf(a.bn_var[col] + a.bn_eps);
+                bn_pre[0] = invstd * a.bn_w[col];
+                bn_pre[1] = a.bn_b[col] - a.bn_mean[col] * bn_pre[0];
+            }
+        }
+    } else {
+        // ---- computing waves
+        // the tile's banded entries: one 16-byte load per (target, slot), in flight across the main loop
+#pragma unroll
+        for (int c = 0; c < NE; ++c) {
+            const int idx = tid + 256 * c, lo = idx >> 3;
+            const int i = own0 + lo;
+            f32x4 e = {0.f, 0.f, 0.f, __int_as_float(-1)};
+            if (lo < OWN && i < M) e = a.ent[(long long)i * SLOTS + (idx & 7)];
+            pe[c] = e;
+        }
+        const int boff = (BM + 16 * wave + r) * 64, xoff = (BM + 64 + r) * 64, aoff = r * 64;
+        const int x0 = aoff + (wave < ACC ? wave : 0) * 1024, x1 = aoff + (wave + 4 < ACC ? wave + 4 : 0) * 1024;
+        auto frags = [&](const float *st, int d, f32x4 &bv, f32x4 &bx, f32x4 (&av)[ACC], f32x4 (&ax)[2]) {
+            const int slot = 4 * ((4 * d + q) ^ r);
+            bv = *reinterpret_cast<const f32x4 *>(&st[boff + slot]);
+#pragma unroll
+            for (int h = 0; h < ACC; ++h) av[h] = *reinterpret_cast<const f32x4 *>(&st[aoff + h * 1024 + slot]);
+            if (nA > 0) {
+                bx = *reinterpret_cast<const f32x4 *>(&st[xoff + slot]);
+                ax[0] = *reinterpret_cast<const f32x4 *>(&st[x0 + slot]);
+            }
+            if (ACC > 4 && nA > 1) ax[1] = *reinterpret_cast<const f32x4 *>(&st[x1 + slot]);
+        };
+        auto mfmas = [&](const f32x4 &bv, const f32x4 &bx, const f32x4 (&av)[ACC], const f32x4 (&ax)[2], int t0, int t1) {
+#pragma unroll
+            for (int t = t0; t < t1; ++t) {
+#pragma unroll
+                for (int h = 0; h < ACC; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
+                if (nA > 0) accx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0][t], bx[t], accx[0], 0, 0, 0);
+                if (ACC > 4 && nA > 1) accx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1][t], bx[t], accx[1], 0, 0, 0);
+            }
+        };
+        asm volatile("s_barrier" ::: "memory");                    // barrier 0
+        f32x4 bv0, bv1, bx0 = zero, bx1 = zero, av0[ACC], av1[ACC], ax0[2] = {zero, zero}, ax1[2] = {zero, zero};
+        frags(gemm_lds, 0, bv0, bx0, av0, ax0);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const float *st = gemm_lds + (ch % NST) * STAGE;
+            const float *nx = gemm_lds + ((ch + 1) % NST) * STAGE;
+            const bool last = ch + 1 == nchunks;
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(bv0, bx0, av0, ax0, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            frags(st, 1, bv1, bx1, av1, ax1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(bv0, bx0, av0, ax0, 2, 4);
+            mfmas(bv1, bx1, av1, ax1, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            frags(st, 2, bv0, bx0, av0, ax0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(bv1, bx1, av1, ax1, 2, 4);
+            mfmas(bv0, bx0, av0, ax0, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            frags(st, 3, bv1, bx1, av1, ax1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(bv0, bx0, av0, ax0, 2, 4);
+            mfmas(bv1, bx1, av1, ax1, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!last) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier ch + 1
+                frags(nx, 0, bv0, bx0, av0, ax0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(bv1, bx1, av1, ax1, 2, 4);
+        }
+    }
+    __syncthreads();                                               // nothing in flight, every operand read done
+
+    // ---- h tile, attention columns, folded BatchNorm and the entries go to LDS
+    float *Cs = gemm_lds;
+    if (wave8 >= 4) {
+        if (tid < 256 + 64) {
+            Cs[O_BN + tid - 256] = bn_pre[0];
+            Cs[O_BN + 64 + tid - 256] = bn_pre[1];
+            Cs[O_BN + 128 + tid - 256] = bn_pre[2];
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < ACC; ++h)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)                      // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+                Cs[(16 * h + 4 * q + reg) * LD + 16 * wave + r] = acc[h][reg];
+        if (r < 2) {                                               // column 0 of the attention block = a_src, column 1 = a_dst
+            float *dst = Cs + (r == 0 ? O_AS : O_AD);
+            if (nA > 0)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dst[16 * wave + 4 * q + reg] = accx[0][reg];
+            if (ACC > 4 && nA > 1)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dst[16 * (wave + 4) + 4 * q + reg] = accx[1][reg];
+        }
+        const bool use_edge = a.v != nullptr;
+        const float v0 = use_edge ? a.v[0] : 0.0f, v1 = use_edge ? a.v[1] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < NE; ++c) {
+            const int idx = tid + 256 * c;
+            if (idx < OWN * SLOTS) {
+                const f32x4 e = pe[c];
+                const int eidx = __float_as_int(e.w);
+                int jl = __float_as_int(e.x) - rowbase;            // tile row of the source
+                jl = (eidx >= 0 && jl >= 0 && jl < BM) ? jl : (idx >> 3) + HALO;      // empty slot: the target's own row, weight 0
+                const float t = use_edge ? __builtin_fmaf(e.z, v1, e.y * v0) : 0.0f;  // gat_aggregate_kernel's edge term
+                *reinterpret_cast<f32x4 *>(&Cs[O_EN + 4 * idx]) = f32x4{__int_as_float(jl), t, e.w, 0.f};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- attention + aggregation: a 16-lane group per target (4 targets per wave), lane s = entry slot s and column quad s
+    const int grp = tid >> 4, s16 = tid & 15;
+    const f32x4 bnsc = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 4 * s16]);
+    const f32x4 bnsh = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 64 + 4 * s16]);
+    const f32x4 bnbi = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 128 + 4 * s16]);
+    constexpr int NPASS = (OWN + 31) / 32;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int lo = pass * 32 + grp, i = own0 + lo;
+        const bool live = lo < OWN && i < M;                       // uniform over the 16-lane group
+        const int lc = live ? lo : 0;
+        f32x4 rs = zero;
+        if (live && a.resid) rs = *reinterpret_cast<const f32x4 *>(a.resid + (long long)i * K + n0 + 4 * s16);
+        f32x4 en = {__int_as_float(lc + HALO), 0.f, __int_as_float(-1), 0.f};
+        if (s16 < SLOTS) en = *reinterpret_cast<const f32x4 *>(&Cs[O_EN + 4 * (lc * SLOTS + s16)]);
+        const int jl = __float_as_int(en.x), eidx = __float_as_int(en.z);
+        const bool valid = eidx >= 0;
+        float l = -INFINITY;
+        if (valid) {
+            l = (Cs[O_AS + jl] + Cs[O_AD + lc + HALO]) + en.y;
+            l = l > 0.0f ? l : a.slope * l;                        // leaky_relu
+        }
+        const float m = group16_max(l);
+        const float p = valid ? expf(l - m) : 0.0f;
+        const float den = group16_sum(p) + 1e-16f;                 // PyG softmax
+        const float al = p / den;
+        if (a.alpha_out && valid && live && n0 == 0) a.alpha_out[eidx] = al;
+        f32x4 o = zero;
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {                          // entries in CSR order, self loop last
+            const float at = __shfl(al, t, 16);
+            const int jt = __shfl(jl, t, 16);
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&Cs[jt * LD + 4 * s16]);
+            o.x = __builtin_fmaf(at, gv.x, o.x);
+            o.y = __builtin_fmaf(at, gv.y, o.y);
+            o.z = __builtin_fmaf(at, gv.z, o.z);
+            o.w = __builtin_fmaf(at, gv.w, o.w);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = o[t] + bnbi[t];
+            if (a.bn_w) v = v * bnsc[t] + bnsh[t];
+            if (a.relu) v = fmaxf(v, 0.0f);
+            if (a.resid) v += rs[t];
+            o[t] = v;
+        }
+        if (live) *reinterpret_cast<f32x4 *>(a.out + (long long)i * K + n0 + 4 * s16) = o;
+    }
+}
+
+// Tile of the fused layer: 16 ACC rows computed, 16 ACC - 4 owned, 64 columns; the cost of a workgroup is the MFMA time of
+// its busiest computing wave (ACC main accumulators + its share of the ACC attention row blocks) + what a round costs besides.
+inline int band_pick_acc(int M, int H)
+{
+    const long long nch = H / 64, ncb = H / 64;
+    int best = 1;
+    long long best_cost = -1;
+    for (int acc = 1; acc <= 6; ++acc) {
+        const int own = 16 * acc - 2 * NSC_BAND_HALO;
+        const long long tiles = ncb * ((M + own - 1) / own);
+        const long long rounds = (tiles + 255) / 256;
+        const long long cost = rounds * ((acc + (acc + 3) / 4) * nch * 512 + 3000);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = acc; }
+    }
+    return best;
+}
+
+template <int ACC>
+bool launch_banded_cfg(hipStream_t st, const BandArgs &a)
+{
+    constexpr unsigned lds = 3 * (16 * ACC + 80) * 256;
+    static_assert(lds <= 160 * 1024, "LDS of a CU");
+    if (lds > 64 * 1024) {                                         // per-device opt-in, as launch_glds_cfg
+        static std::atomic<int> opted[16];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+        int s = opted[dev].load(std::memory_order_acquire);
+        if (s == 0) {
+            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gat_layer_banded_kernel<ACC, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 2;
+            opted[dev].store(s, std::memory_order_release);
+        }
+        if (s != 1) return false;
+    }
+    constexpr int own = 16 * ACC - 2 * NSC_BAND_HALO;
+    const dim3 grid(a.H / 64, (a.M + own - 1) / own);
+    hipLaunchKernelGGL((gat_layer_banded_kernel<ACC, 3>), grid, dim3(512), lds, st, a);
+    return true;
+}
+
+// false: this layer cannot take the fused kernel here (the caller runs lin GEMM + gat_aggregate_kernel: same bits)
+inline bool launch_banded_layer(hipStream_t st, const BandArgs &a)
+{
+    if (a.H < 64 || (a.H & 63) || (reinterpret_cast<unsigned long long>(a.A) & 15) ||
+        (reinterpret_cast<unsigned long long>(a.B) & 15) || (reinterpret_cast<unsigned long long>(a.Bx) & 15) ||
+        (reinterpret_cast<unsigned long long>(a.out) & 15) || (a.resid && (reinterpret_cast<unsigned long long>(a.resid) & 15)))
+        return false;
+    switch (band_pick_acc(a.M, a.H)) {
+    case 1: return launch_banded_cfg<1>(st, a);
+    case 2: return launch_banded_cfg<2>(st, a);
+    case 3: return launch_banded_cfg<3>(st, a);
+    case 4: return launch_banded_cfg<4>(st, a);
+    case 5: return launch_banded_cfg<5>(st, a);
+    default: return launch_banded_cfg<6>(st, a);
+    }
+}

@@ -67,6 +67,21 @@ class GraphCSR:
         _lib.check(st, "nsc_graph_build_csr")
 
         self.t_ptr = self.t_entry = self.tgt = None
+        # Banded form (nsc_graph_band_entries): the temporal chain of every reference caller has its sources within 2 rows
+        # of the target (graph_manager.py:520-532), and such a graph runs a GATConv layer as ONE launch.  Whether THIS graph
+        # qualifies is read back once per graph (two int32; the CSR is cached per graph by SpectralGNN._csr).
+        self.band, self.band_entries = 0, None
+        if n_nodes > 0 and self.edge_dim in (0, 2):
+            ent = torch.empty((n_nodes, 8, 4), dtype=torch.float32, device=dev)
+            info = torch.empty(2, dtype=torch.int32, device=dev)
+            g = self.struct()
+            with torch.cuda.device(dev):
+                st = L.nsc_graph_band_entries(C.byref(g), _lib.ptr(ea), self.edge_dim, _lib.ptr(ent), _lib.ptr(info),
+                                              _lib.stream_ptr(dev))
+            _lib.check(st, "nsc_graph_band_entries")
+            max_off, max_deg = info.tolist()
+            if max_off <= 2 and max_deg <= 8:
+                self.band, self.band_entries = 2, ent
 
     def ensure_transpose(self):
         """Entries grouped by source (nsc_graph_transpose); the backward needs it, built once."""
@@ -95,6 +110,8 @@ class GraphCSR:
         g.loop_attr = self.loop_attr.data_ptr() if self.loop_attr is not None else None
         if self.t_ptr is not None:
             g.t_ptr, g.t_entry, g.tgt = self.t_ptr.data_ptr(), self.t_entry.data_ptr(), self.tgt.data_ptr()
+        if getattr(self, "band", 0):
+            g.band_entries, g.band = self.band_entries.data_ptr(), self.band
         return g
 
 
@@ -197,7 +214,8 @@ class SpectralGNN(nn.Module):
         # True: launch the LDS-free, low-VGPR kernel set (NSC_GAT_CORESIDENT) whose workgroups fit beside a
         # resident encoder grid -- used by distributed.ShardedDescriptorPath(pipeline=True).  "shared_b": that set with
         # the small-LDS GEMMs (NSC_GAT_SHARED_B).  "lds_tiled": the stand-alone forward with the round-2 GEMMs
-        # (NSC_GAT_LDS_TILED) instead of the LDS-DMA GEMM.  Same output, bit for bit.
+        # (NSC_GAT_LDS_TILED) instead of the LDS-DMA GEMM.  "generic": the stand-alone forward without the one-launch
+        # layers of a banded graph (NSC_GAT_GENERIC).  Same output, bit for bit.
         self.coresident = False
         self._seed_dev = None              # device int64[1]: dropout seed read by the kernels at run time (captured steps)
         self._direct_grads = False         # backward adds straight into the parameters' .grad tensors (GNNTrainer's steps)
@@ -353,7 +371,7 @@ class SpectralGNN(nn.Module):
         with torch.cuda.device(dev):
             st = L.nsc_gat_forward_ex(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
                                       _lib.ptr(out), _lib.ptr(alpha), _lib.ptr(ws), nbytes,
-                                      {False: 0, True: 1, "shared_b": 3, "lds_tiled": 4}[getattr(self, "coresident", False)],
+                                      {False: 0, True: 1, "shared_b": 3, "lds_tiled": 4, "generic": 8}[getattr(self, "coresident", False)],
                                       _lib.stream_ptr(dev))
         _lib.check(st, "nsc_gat_forward_ex")
         return out, alpha, csr

@@ -59,7 +59,7 @@ def test_argument_validation_without_gpu(lib):
     lib.nsc_enc_default_params(C.byref(p))
     assert (p.n_elevation, p.n_azimuth, p.n_bins, p.target_rows) == (16, 360, 50, 16)
     assert abs(p.elev_min_rad - np.deg2rad(-24.8)) < 1e-15
-    assert lib.nsc_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.nsc_abi_version() == _lib.ABI_VERSION == 4
     # errors are reported before anything is launched
     assert lib.nsc_encode_clouds(None, None, 1, 10, 4, p, None, None, None, None, None, 0, None) == -1
     assert lib.nsc_encode_clouds(None, None, 0, 0, 4, p, None, None, None, None, None, 0, None) == 0

@@ -285,3 +285,97 @@ def test_pipelined_path_options_match_serial(opts):
                 assert torch.equal(wd, gd) and torch.equal(we, ge)
             assert not torch.equal(want2[0][1], want[0][1])
     m.gnn.coresident = False
+
+
+# ---- round 4: one-launch GATConv layers on banded graphs (gat_layer_banded_kernel) ---------------------------------------
+def _banded_vs_generic(m, g, want_band=2):
+    """The default forward takes the banded kernel when the graph qualifies; "generic" (NSC_GAT_GENERIC) forces lin GEMM +
+    gat_aggregate_kernel.  Same bits."""
+    use_edge = getattr(g, "edge_attr", None) is not None and m.gnn.edge_dim is not None
+    with torch.no_grad():
+        m.gnn.coresident = False
+        a = m(g)
+        assert m.gnn._csr(g, use_edge).band == want_band
+        m.gnn.coresident = "generic"
+        b = m(g)
+        m.gnn.coresident = False
+    assert torch.equal(a, b)
+    return a
+
+
+# sizes either side of the owned-row counts of the tiles (12, 28, 44, 60, 76, 92 rows) and of the tile switches
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 11, 12, 13, 28, 29, 57, 75, 76, 77, 153, 1023, 1024, 3000, 4541, 7000])
+@pytest.mark.parametrize("edge_dim", [2, None])
+def test_banded_layer_kernel_is_bit_identical(n, edge_dim):
+    m = _model(edge_dim=edge_dim)
+    g = gm.synthetic_chain_graph(n, device="cuda", seed=n + 17)
+    out = _banded_vs_generic(m, g)
+    if n <= 1024:
+        _check(out, m, g)
+
+
+@pytest.mark.parametrize("tn", [1, 3, 5])
+def test_banded_other_bandwidths_and_hidden(tn):
+    """temporal_neighbors 1 (self loops only), 3 (one neighbour each side), 5; hidden 64 / 128 (1 / 2 column blocks, 1 / 2
+    k-chunks), no BatchNorm-free path exists, residual on the middle layer of 3."""
+    for hidden in (64, 128):
+        m = _model(edge_dim=2, hidden_dim=hidden, input_dim=48, output_dim=80)
+        g = gm.synthetic_chain_graph(97, device="cuda", seed=tn, temporal_neighbors=tn)
+        g.x = torch.rand((97, 48), device="cuda")
+        out = _banded_vs_generic(m, g)
+        _check(out, m, g)
+
+
+def test_banded_shuffled_and_duplicate_edges():
+    """A banded multigraph: the chain's edges in random order, some twice, explicit self loops (removed and re-added) --
+    at most 8 entries per target, so it still takes the banded kernel; entry order = edge order decides the summation."""
+    rng = np.random.default_rng(3)
+    n = 203
+    base = gm.chain_edges(n, 5)
+    extra = base[rng.choice(len(base), 150, replace=False)]
+    loops = np.stack([np.arange(0, n, 7), np.arange(0, n, 7)], 1)
+    edges = np.concatenate([base, extra, loops], 0)
+    rng.shuffle(edges)
+    # no target above 7 real edges (+ the self loop = 8 slots)
+    keep, cnt = [], np.zeros(n, int)
+    for s, t in edges:
+        if s == t or cnt[t] < 7:
+            keep.append((s, t))
+            cnt[t] += s != t
+    ei = torch.tensor(np.array(keep), dtype=torch.long).t().contiguous().cuda()
+    ea = torch.rand(ei.shape[1], 2).cuda()
+    g = gm.Data(x=torch.rand(n, 800).cuda(), edge_index=ei, edge_attr=ea, num_nodes=n)
+    m = _model()
+    out = _banded_vs_generic(m, g)
+    _check(out, m, g)
+
+
+def test_not_banded_graphs_keep_the_generic_kernels():
+    """A loop closure (|i - j| > 2), a target with more than 8 entries, edge_dim 3: band stays 0, results as before."""
+    m = _model()
+    g = gm.synthetic_chain_graph(120, device="cuda", seed=4)
+    ei = torch.cat([g.edge_index, torch.tensor([[3, 90], [90, 3]], device="cuda")], 1)
+    ea = torch.cat([g.edge_attr, torch.rand(2, 2, device="cuda")], 0)
+    g2 = gm.Data(x=g.x, edge_index=ei, edge_attr=ea, num_nodes=120)
+    _check(_banded_vs_generic(m, g2, want_band=0), m, g2)
+    dup = torch.tensor([[11] * 6, [12] * 6], device="cuda")
+    g3 = gm.Data(x=g.x, edge_index=torch.cat([g.edge_index, dup], 1),
+                 edge_attr=torch.cat([g.edge_attr, torch.rand(6, 2, device="cuda")], 0), num_nodes=120)
+    _check(_banded_vs_generic(m, g3, want_band=0), m, g3)
+    m3 = _model(edge_dim=3)
+    g4 = gm.Data(x=g.x, edge_index=g.edge_index, edge_attr=torch.rand(g.edge_index.shape[1], 3, device="cuda"), num_nodes=120)
+    _check(_banded_vs_generic(m3, g4, want_band=0), m3, g4)
+
+
+def test_banded_attention_coefficients():
+    """forward_with_attention through the banded kernel returns the generic kernels' coefficients, bit for bit."""
+    m = _model(edge_dim=None)
+    g = gm.synthetic_chain_graph(150, device="cuda", seed=8)
+    with torch.no_grad():
+        out_a, att_a = m.gnn.forward_with_attention(g)
+        m.gnn.coresident = "generic"
+        out_b, att_b = m.gnn.forward_with_attention(g)
+        m.gnn.coresident = False
+    assert torch.equal(out_a, out_b)
+    for (ea, aa), (eb, ab) in zip(att_a, att_b):
+        assert torch.equal(ea, eb) and torch.equal(aa, ab)

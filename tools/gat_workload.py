@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The GAT half of the path as a stand-alone workload for rocprofv3 (BASELINE configs[2]): 3-layer GAT forward,
 800 -> 256 -> GATx3 -> 800, edge_dim = 2, eval mode, over a KITTI-00-shaped temporal chain (N keyframes, 5 temporal
-neighbours).  usage: gat_workload.py [N=4541] [reps=50] [coresident=0]
+neighbours).  usage: gat_workload.py [N=4541] [reps=50] [kernel set: 0 default (banded layers), 1 co-resident, 2 generic stand-alone]
 Prints the average forward time measured with HIP events (un-profiled runs) -- under the profiler use the trace."""
 import os
 import sys
@@ -21,7 +21,7 @@ torch.manual_seed(0)
 m = create_spectral_gnn(edge_dim=2)
 go.randomize_bn_stats(m)
 m = m.to("cuda").eval()
-m.gnn.coresident = bool(cores)
+m.gnn.coresident = {0: False, 1: True, 2: "generic"}[cores]
 g = gm.synthetic_chain_graph(n, device="cuda", seed=1)
 with torch.no_grad():
     for _ in range(10):
@@ -35,5 +35,5 @@ with torch.no_grad():
     torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / reps * 1e3
 flop = 2.0 * n * (800 * 256 + 3 * 256 * 256 + 256 * 800)
-print(f"N={n} coresident={cores}: {us:.1f} us per forward = {flop / us / 1e6:.1f} TFLOP/s of f32 MFMA work "
+print(f"N={n} kernel set {cores}: {us:.1f} us per forward = {flop / us / 1e6:.1f} TFLOP/s of f32 MFMA work "
       f"({flop / us / 1e6 / 157.3 * 100:.1f} % of 157.3 TF)", flush=True)

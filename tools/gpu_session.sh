@@ -51,7 +51,7 @@ run_step() {
     gat)
         cd $R; timeout -k 10 900 python -m pytest tests/test_gat_gpu.py -x -q -m gpu > $O/pytest_gat.log 2>&1; rc=$?
         tail -3 $O/pytest_gat.log; [ $rc -eq 0 ] || return 1
-        for a in "4541 200 0" "1024 200 0" "4541 200 1" "1024 200 1"; do python tools/gat_workload.py $a >> $O/gat_time.log 2>&1 || return 1; done
+        for a in "4541 200 0" "1024 200 0" "4541 200 2" "1024 200 2" "4541 200 1" "1024 200 1"; do python tools/gat_workload.py $a >> $O/gat_time.log 2>&1 || return 1; done
         grep -v amdgpu.ids $O/gat_time.log
         cd /tmp
         for n in 4541 1024; do

@@ -10,6 +10,6 @@ for n in (4541, 1024):
         continue
     print("N", n)
     for r in csv.DictReader(open(fs[0])):
-        if "gemm" in r["Name"] or "aggregate" in r["Name"]:
+        if "gemm" in r["Name"] or "aggregate" in r["Name"] or "banded" in r["Name"]:
             print("  %-72s calls %4d avg %.2f us min %.2f" % (r["Name"][28:100], int(r["Calls"]),
                                                               float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))

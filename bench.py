@@ -540,6 +540,9 @@ def main():
             f = [int(v) for v in spec.split(":")]
             self.mode, self.wgs, self.per_wave, self.launches = f[0], f[1], f[2], (f[3] if len(f) > 3 else 1)
             self.L, self.lib = L_, L_.lib()
+            if not hasattr(self.lib, "nsc_debug_burn"):
+                raise SystemExit("--gnn-burn needs a development build of the library (NSC_DEV_BUILD=1 python "
+                                 "neural-spectral-codec_amd/build.py): the product library has no nsc_debug_burn")
             self.scratch = torch.rand(1 << 19, dtype=torch.float32, device=dev)          # 2 MB
 
         def __call__(self, g):

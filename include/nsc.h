@@ -130,11 +130,6 @@ int nsc_interpolate_range_images(const float *imgs, int32_t n_images, int32_t ro
 int    nsc_interpolate_range_images_ex(const float *imgs, int32_t n_images, int32_t rows, const int32_t *lut,
                                        int32_t method, float *out, void *stream);
 
-/* Parity triage: per point, the pixel index row*360+col the scatter uses (-1 = dropped) and
- * whether the exact (float64 atan2) path decided it (bit0 azimuth, bit1 elevation). */
-int nsc_debug_point_bins(const float *pts, int64_t n_points, int32_t stride_floats,
-                         const NscEncParams *p, int32_t *out_idx, uint8_t *out_flags /*nullable*/,
-                         void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * GNN enhancer: Linear 800->256 + BN + ReLU, 3 x GATConv(256->256, heads=1, edge_dim) + BN,
@@ -243,13 +238,6 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
 #define NSC_GAT_GENERIC 8u
 int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, const float *edge_attr,
                        float *out, float *alpha_out, void *ws, size_t ws_bytes, uint32_t flags, void *stream);
-/* Diagnostic co-runner (bench.py --gnn-burn): `workgroups` x 4 waves of the co-resident GNN kernels' footprint (0 B of LDS,
- * < 56 VGPRs), each wave issuing `per_wave` operations of ONE kind -- mode 0: v_mfma_f32_16x16x4_f32 on register operands
- * (4 independent accumulators), 1: v_fma_f32 (64 lanes), 2: 16-byte loads from a 1 MB L2-resident buffer (`scratch`, >= 1 MB),
- * 3: ds_bpermute_b32, 4: 16-byte loads that hit L1 (every wave the same 16 KB), 5: 16-byte loads of which the four waves of a
- * workgroup read the same addresses.  Answers what a given amount of one resource costs the kernel it runs beside.  scratch also takes the
- * (never read) results. */
-int nsc_debug_burn(int32_t mode, int32_t workgroups, int32_t per_wave, float *scratch, size_t scratch_bytes, void *stream);
 /* Which tile the default (LDS-DMA) GEMM takes for C[M,N] = A[M,K] B[N,K]^T -- host function, no device work: rows and
  * columns of a workgroup tile, its LDS bytes and the number of workgroups (a grid of at most 256 is one round on the
  * 256 CUs).  Returns NSC_OK, or NSC_EINVAL for non-positive sizes / K not a multiple of 16. */

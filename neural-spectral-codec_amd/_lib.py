@@ -1,7 +1,9 @@
 """ctypes binding of csrc/libnsc_hip.so (include/nsc.h).  No fallback: if the library is missing
 or a call fails, this raises."""
+import collections
 import ctypes as C
 import os
+import threading
 
 import torch  # noqa: F401  -- loads torch's libamdhip64 first so the library shares its HIP runtime
 
@@ -102,7 +104,6 @@ SYMBOLS = {
     "nsc_interpolate_range_images": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "nsc_interpolate_range_images_ex": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "nsc_encode_range_images": (C.c_int, [_vp, _i32, _i32, _pp, _vp, _vp, _vp]),
-    "nsc_debug_point_bins": (C.c_int, [_vp, _i64, _i32, _pp, _vp, _vp, _vp]),
     "nsc_graph_workspace_bytes": (_sz, [_i32, _i64]),
     "nsc_graph_build_csr": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nsc_graph_band_entries": (C.c_int, [C.POINTER(Graph), _vp, _i32, _vp, _vp, _vp]),
@@ -113,7 +114,6 @@ SYMBOLS = {
     "nsc_gat_forward_ex": (C.c_int, [C.POINTER(GatModel), C.POINTER(Graph), _vp, _vp, _vp, _vp, _vp, _sz, C.c_uint32,
                                      _vp]),
     "nsc_gat_gemm_tile": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "nsc_debug_burn": (C.c_int, [_i32, _i32, _i32, _vp, _sz, _vp]),
     "nsc_graph_transpose_workspace_bytes": (_sz, [_i32]),
     "nsc_graph_transpose": (C.c_int, [C.POINTER(Graph), _vp, _vp, _vp, _vp, _sz, _vp]),
     "nsc_gat_train_workspace_bytes": (_sz, [C.POINTER(GatModel), C.POINTER(Graph)]),
@@ -148,6 +148,14 @@ SYMBOLS = {
 }
 
 
+# include/nsc_debug.h: diagnostics outside the product ABI, bound when the library exports them (nsc_debug_burn: development
+# builds only)
+DEBUG_SYMBOLS = {
+    "nsc_debug_point_bins": (C.c_int, [_vp, _i64, _i32, _pp, _vp, _vp, _vp]),
+    "nsc_debug_burn": (C.c_int, [_i32, _i32, _i32, _vp, _sz, _vp]),
+}
+
+
 def lib():
     """Load the HIP library (once).  Raises NscError if it has not been built."""
     global _lib
@@ -161,6 +169,11 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DEBUG_SYMBOLS.items():
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         if L.nsc_abi_version() != ABI_VERSION:
             raise NscError("libnsc_hip.so ABI version mismatch")
         _lib = L
@@ -186,3 +199,64 @@ def require_cuda(t, name):
     if not t.is_cuda:
         raise NscError(f"{name} must live on a HIP device (got {t.device}); the MI355X path has no "
                        "CPU fallback -- move the module/tensors to 'cuda'")
+
+
+class ScratchCache:
+    """Device scratch buffers of the Python layer (CSR build, GNN forward workspace, split encoder), one set per
+    (device, stream, host thread, use): work on different streams may overlap and two host threads issuing on one stream
+    interleave their launches, work issued by one thread on one stream is ordered.
+
+    Bounded (round 4): at most ``cap`` keys, least recently used first, keys of host threads that no longer exist before
+    any other.  A buffer is NEVER replaced by a bigger one -- a larger request adds a buffer to the key and the smaller
+    ones stay, because a captured hipGraph replays the address it recorded; keys touched while a stream capture is open
+    are pinned until ``release()`` (a replay does not come through here, so use-recency says nothing about them)."""
+
+    def __init__(self, cap: int = 48):
+        self.cap = cap
+        self._lock = threading.Lock()
+        self._d = collections.OrderedDict()          # key -> [pinned, [tensors, ascending size]]
+
+    def get(self, device, nbytes: int, tag: str = ""):
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), tag)
+        capturing = torch.cuda.is_current_stream_capturing()
+        with self._lock:
+            ent = self._d.get(key)
+            if ent is None:
+                ent = self._d[key] = [False, []]
+            else:
+                self._d.move_to_end(key)
+            ent[0] = ent[0] or capturing
+            for t in ent[1]:
+                if t.numel() >= nbytes:
+                    return t
+            big = ent[1][-1].numel() if ent[1] else 0
+            t = torch.empty(max(int(nbytes), 256, 2 * big if big else 0), dtype=torch.uint8, device=device)
+            ent[1].append(t)
+            if len(self._d) > self.cap:
+                self._prune()
+            return t
+
+    def _prune(self):
+        alive = {th.ident for th in threading.enumerate()}
+        for dead_first in (True, False):
+            for k in list(self._d):
+                if len(self._d) <= self.cap:
+                    return
+                pinned = self._d[k][0]
+                if pinned or (dead_first and k[2] in alive):
+                    continue
+                del self._d[k]
+
+    def release(self, device=None):
+        """Drop every buffer (of ``device``), pinned ones included: call when no captured hipGraph that ran through this
+        cache will be replayed any more (e.g. after tearing down a ShardedDescriptorPath / GNNTrainer)."""
+        with self._lock:
+            for k in list(self._d):
+                if device is None or k[0] == str(device):
+                    del self._d[k]
+
+    def __len__(self):
+        return len(self._d)
+
+
+scratch = ScratchCache()

@@ -24,6 +24,7 @@
 #include <utility>
 
 #include "../../include/nsc.h"
+#include "../../include/nsc_debug.h"
 #include "nsc_math.h"
 
 namespace {
@@ -1609,20 +1610,3 @@ int nsc_debug_point_bins(const float *pts, int64_t n_points, int32_t stride, con
 }
 
 }  // extern "C"
-
-#ifdef NSC_DEV_TUNING
-// Development only (tools/overlap_probe.py): an ALU-bound, LDS-free, low-VGPR filler kernel.
-namespace {
-__global__ __launch_bounds__(256) void dev_spin_kernel(int iters, float *sink)
-{
-    float a = threadIdx.x * 1e-3f, b = 1.0001f;
-    for (int i = 0; i < iters; ++i) a = __builtin_fmaf(a, b, 1e-7f);
-    if (a == 123.456f) sink[0] = a;
-}
-}  // namespace
-extern "C" int nsc_dev_spin(int wgs, int iters, float *sink, void *stream)
-{
-    hipLaunchKernelGGL(dev_spin_kernel, dim3(wgs), dim3(256), 0, static_cast<hipStream_t>(stream), iters, sink);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
-}
-#endif

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "../../include/nsc.h"
+#include "../../include/nsc_debug.h"
 
 namespace {
 
@@ -163,11 +164,13 @@ struct PrepArgs {
     int H, edge_dim;
 };
 
-// grid (n_layers, 3): y = 0 -> u_src, 1 -> u_dst, 2 -> v.  folded layout per layer: [u_src H][u_dst H][v 8]
+// grid (n_layers, 3): y = 0 -> u_src, 1 -> u_dst, 2 -> v.  folded layout per layer (fold_stride(H) floats): [u_src H][u_dst H][v 8]
+__host__ __device__ inline int fold_stride(int H) { return 2 * H + NSC_GAT_MAX_EDGE_DIM; }
+
 __global__ __launch_bounds__(256) void gat_fold_kernel(PrepArgs a, float *__restrict__ folded)
 {
     const int l = blockIdx.x, which = blockIdx.y, H = a.H;
-    float *dst = folded + (long long)l * (2 * H + NSC_GAT_MAX_EDGE_DIM);
+    float *dst = folded + (long long)l * fold_stride(H);
     if (which < 2) {
         const float *att = which == 0 ? a.l[l].att_src : a.l[l].att_dst;
         const float *w = a.l[l].w;
@@ -841,7 +844,9 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(AggArgs a)
     }
 }
 
-// Diagnostic co-runner (nsc_debug_burn): one kind of operation per launch, in the co-resident kernels' footprint.
+#ifdef NSC_DEV_TUNING
+// Diagnostic co-runner (nsc_debug_burn, development builds only): one kind of operation per launch, in the co-resident
+// kernels' footprint.
 __global__ __launch_bounds__(256) void burn_kernel(int mode, int per_wave, float *__restrict__ scratch)
 {
     const int lane = threadIdx.x & 63;
@@ -884,6 +889,8 @@ __global__ __launch_bounds__(256) void burn_kernel(int mode, int per_wave, float
     if (mode == 0) v = (acc[0].x + acc[1].y) + (acc[2].z + acc[3].w);
     if (v == 12345.678f) scratch[(1u << 18) + (gid & 1023u)] = v;          // keeps the work alive; practically never true
 }
+
+#endif  // NSC_DEV_TUNING
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -1076,7 +1083,7 @@ int nsc_graph_band_entries(const NscGraph *g, const float *edge_attr, int32_t ed
 size_t nsc_gat_folded_floats(const NscGatModel *m)
 {
     if (check_model(m) != NSC_OK) return 0;
-    return (size_t)m->n_layers * (2 * m->hidden + NSC_GAT_MAX_EDGE_DIM);
+    return (size_t)m->n_layers * fold_stride(m->hidden);
 }
 
 int nsc_gat_fold_weights(const NscGatModel *m, float *folded, void *stream_)
@@ -1111,6 +1118,7 @@ int nsc_gat_forward(const NscGatModel *m, const NscGraph *g, const float *x, con
     return nsc_gat_forward_ex(m, g, x, edge_attr, out, alpha_out, ws, ws_bytes, 0u, stream_);
 }
 
+#ifdef NSC_DEV_TUNING
 int nsc_debug_burn(int32_t mode, int32_t workgroups, int32_t per_wave, float *scratch, size_t scratch_bytes, void *stream_)
 {
     if (mode < 0 || mode > 5 || workgroups < 0 || per_wave < 0 || !scratch || scratch_bytes < (1u << 20)) return NSC_EINVAL;
@@ -1118,6 +1126,7 @@ int nsc_debug_burn(int32_t mode, int32_t workgroups, int32_t per_wave, float *sc
     hipLaunchKernelGGL(burn_kernel, dim3((unsigned)workgroups), dim3(256), 0, static_cast<hipStream_t>(stream_), mode, per_wave, scratch);
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
+#endif
 
 int nsc_gat_gemm_tile(int32_t M, int32_t N, int32_t K, int32_t *tile_rows, int32_t *tile_cols, int32_t *lds_bytes,
                       int64_t *workgroups)
@@ -1172,7 +1181,7 @@ int nsc_gat_forward_ex(const NscGatModel *m, const NscGraph *g, const float *x, 
     float *cur = h0, *nxt = h1;
     for (int l = 0; l < L; ++l) {
         const NscGatLayer &Ly = m->layers[l];
-        const float *auxl = aux + (size_t)l * (2 * H + NSC_GAT_MAX_EDGE_DIM);
+        const float *auxl = aux + (size_t)l * fold_stride(H);
         if (banded) {
             BandArgs b = {};
             b.A = cur; b.B = Ly.lin_w; b.Bx = auxl; b.M = N; b.H = H;

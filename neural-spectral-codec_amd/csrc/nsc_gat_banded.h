@@ -8,16 +8,31 @@
 // h = x W^T plus a 2-row halo either side therefore holds every neighbour row the tile's targets aggregate -- the fact
 // distributed.halo_window exploits across GPUs, used here inside one.  A workgroup owns (16 ACC - 4) target rows x 64 output
 // columns: it computes h for 16 ACC rows (the owned rows + halo) x 64 columns on gemm_glds_kernel's main loop (LDS-DMA staging
-// with source-side swizzle, three stages, one raw s_barrier per chunk, four computing + four staging waves), and the two
-// attention columns a_src = x . u_src, a_dst = x . u_dst (nsc_gat_fold_weights) for the same rows as a fifth 16-column block
-// whose row blocks are dealt over the four computing waves.  h stays in LDS: no gat_aggregate_kernel launch, no round trip of
-// h (4.65 MB written + 5 x read at 4 541 keyframes) through L2.
+// with source-side swizzle, three stages, one raw s_barrier per chunk, four computing + four staging waves + two more).  h stays in
+// LDS: no gat_aggregate_kernel launch, no round trip of h (4.65 MB written + 5 x read at 4 541 keyframes) through L2.
 //
-// Bit-identical to the generic kernel sets by construction: every h / a_src / a_dst element is the same MFMA chain (chunk
-// ascending, d = 0..3, t = 0..3, operand element t of lane (r, q) = k 64 c + 16 d + 4 q + t); the softmax reduces with the
-// same xor butterfly (a 16-lane group here, the 64-lane wave there: with at most 16 entries the upper levels of the
-// 64-lane butterfly only add zeros); the aggregation is the same fma chain in CSR entry order; the epilogue is the same
-// expression.  tests/test_gat_gpu.py compares the sets bit for bit.
+// The two attention columns a_src = x . u_src, a_dst = x . u_dst (nsc_gat_fold_weights) of the same rows come off the VALU of
+// two ATTENTION waves (waves 8, 9 of the 640-thread workgroup), one row per lane, from the A chunks the computing waves
+// multiply: v_mfma_f32_16x16x4_f32 is exactly the sequential fused-multiply-add chain over its four k terms in lane-group
+// (q) order -- measured: tools/native/mfma_fma_probe.hip, 409 600 outputs of 256-deep chains over four operand distributions
+// incl. denormal products, 0 differ (the reversed order differs on 54 %) -- so c = fma(x[k], u[k], c) over
+// k = 64 c + 16 d + 4 q + t in the order (c, d, t, q) gives the bits the generic kernels get from a fifth 16-column MFMA block
+// of which 14 columns are waste (a quarter more matrix-pipe time per tile, unevenly dealt: 7 / 6 / 6 / 6 accumulators per
+// wave at 80 rows).  What the chains cost was measured form by form (tools/native/banded_probe.hip, per layer at 4 541
+// keyframes, in-kernel clock; without any chain the kernel takes 12.0 us and its main loop runs at the MFMA issue rate,
+// 10.2 k cycles): the MFMA block 14.6 us; the chains on the STAGING waves 17.5 us (they delay the LDS-DMA issue); on two
+// extra waves fed by scalar loads 15.4 us (five exposed round trips per chunk), by v_readlane from a VGPR 14.2 us, by scalar
+// loads a block ahead 14.0 us, with all 16 LDS reads of a chunk issued up front 13.9 us, + s_setprio 13.6 us (this form);
+// INTERLEAVED with the MFMAs of the computing waves themselves 15.3 us (main loop 19.3 k cycles: a VALU instruction between
+// two MFMAs of a wave costs the matrix pipe its full duration).  In every two-wave form the main loop takes ~14.9 k cycles:
+// a dependent VALU chain in a wave that shares its SIMD with a wave saturating the matrix pipe advances one step per ~58
+// cycles whatever feeds it.
+//
+// Bit-identical to the generic kernel sets by construction: every h element is the same MFMA chain (chunk ascending,
+// d = 0..3, t = 0..3, operand element t of lane (r, q) = k 64 c + 16 d + 4 q + t), a_src / a_dst the same chain as fmas; the
+// softmax reduces with the same xor butterfly (a 16-lane group here, the 64-lane wave there: with at most 16 entries the
+// upper levels of the 64-lane butterfly only add zeros); the aggregation is the same fma chain in CSR entry order; the
+// epilogue is the same expression.  tests/test_gat_gpu.py compares the sets bit for bit.
 //
 // The graph comes as banded entries (nsc_graph_band_entries, built once per graph next to the CSR): 8 slots of 16 bytes per
 // target {source node, edge_attr[0], edge_attr[1], CSR entry index (-1 = empty slot)} in CSR order (self loop last, its
@@ -31,7 +46,7 @@
 struct BandArgs {
     const float *A;              // (M, H) layer input, row stride H
     const float *B;              // (H, H) lin_src.weight
-    const float *Bx;             // folded [u_src H][u_dst H] (rows 0 / 1 of the attention block)
+    const float *Bx;             // folded [u_src H][u_dst H]
     int M, H;
     const f32x4 *ent;            // (M, 8) banded entries
     const float *v;              // folded edge vector (2 floats) or null: no edge term
@@ -41,27 +56,64 @@ struct BandArgs {
     float *alpha_out;            // (nnz) or null
     float bn_eps, slope;
     int relu;
+#ifdef NSC_BAND_CLOCK
+    unsigned long long *clk;     // diagnostic build of tools/native/banded_probe.hip: (tiles, 8) s_memtime stamps
+#endif
 };
 
+#ifdef NSC_BAND_CLOCK
+#define NSC_BAND_STAMP(slot) a.clk[(size_t)tile * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define NSC_BAND_STAMP(slot)
+#endif
+#ifndef NSC_BAND_ABL
+#define NSC_BAND_ABL 0           // ablation builds of the probe (timings only): 1 no aggregation, 2 no attention chains, 4 no entries
+#endif
+
+// counted wait of the staging waves: `pieces` LDS-DMA pieces of younger chunks may stay in flight across the barrier
+template <int NPW> __device__ __forceinline__ void band_wait_barrier(int younger_chunks)
+{
+    switch (younger_chunks) {
+    case 0: glds_wait_barrier<0>(); break;
+    case 1: glds_wait_barrier<NPW>(); break;
+    case 2: glds_wait_barrier<2 * NPW>(); break;
+    default: glds_wait_barrier<3 * NPW>(); break;
+    }
+}
+
+// xor butterflies inside a 16-lane DPP row without the LDS pipe (__shfl_xor compiles to ds_bpermute_b32: a dependent chain of
+// eight LDS round trips per target pass): lane ^ 8 = row_ror:8, lane ^ 4 = row_half_mirror then quad_perm [3,2,1,0]
+// (7 - i = i ^ 7, then ^ 3), lane ^ 2 / ^ 1 = quad_perm [2,3,0,1] / [1,0,3,2].  Same partners, same order of additions as
+// the 64-lane butterfly of gat_aggregate_kernel (whose upper levels add zeros when a target has at most 16 entries).
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float xor8(float v) { return dpp_f<0x128>(v); }
+__device__ __forceinline__ float xor4(float v) { return dpp_f<0x1B>(dpp_f<0x141>(v)); }
+__device__ __forceinline__ float xor2(float v) { return dpp_f<0x4E>(v); }
+__device__ __forceinline__ float xor1(float v) { return dpp_f<0xB1>(v); }
 __device__ __forceinline__ float group16_max(float v)
 {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, xor8(v));
+    v = fmaxf(v, xor4(v));
+    v = fmaxf(v, xor2(v));
+    return fmaxf(v, xor1(v));
 }
 __device__ __forceinline__ float group16_sum(float v)
 {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += xor8(v);
+    v += xor4(v);
+    v += xor2(v);
+    return v + xor1(v);
 }
 
 template <int ACC, int NST = 3>
-__global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
+__global__ __launch_bounds__(640) void gat_layer_banded_kernel(BandArgs a, const float *__restrict__ ux)
 {
     constexpr int HALO = NSC_BAND_HALO, SLOTS = NSC_BAND_SLOTS;
     constexpr int BM = 16 * ACC, OWN = BM - 2 * HALO;              // rows computed / rows owned
-    constexpr int BNR = 80;                                        // B rows of a stage: 64 columns of W + the attention block
+    constexpr int BNR = 64;                                        // B rows of a stage: 64 columns of W
     constexpr int ROWS = BM + BNR, NPW = ROWS / 16, STAGE = ROWS * 64;
     constexpr int LD = 68;                                         // h tile row stride (floats)
     constexpr int NE = (OWN * SLOTS + 255) / 256;                  // banded entries per computing thread
@@ -81,15 +133,54 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
     const int nchunks = K >> 6;                                    // H is a multiple of 64 (host check)
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc[ACC], accx[2] = {zero, zero};
+    if (tid == 0) NSC_BAND_STAMP(0);
+    f32x4 acc[ACC];
 #pragma unroll
     for (int h = 0; h < ACC; ++h) acc[h] = zero;
-    // attention row blocks of this computing wave: h = wave and h = wave + 4
-    const int nA = (wave < ACC ? 1 : 0) + (wave + 4 < ACC ? 1 : 0);
     f32x4 pe[NE];                                                  // prefetched entries (computing waves)
     float bn_pre[3] = {1.f, 0.f, 0.f};
+    // attention chains: lane l of attention wave 8 + a owns tile row 64 a + l (16 consecutive lanes = 16 consecutive rows:
+    // their swizzled reads of one k-quad hit 16 different slots); dead lanes repeat row 0
+    const int xrow = 64 * (wave8 - 8) + lane;
+    const bool xlive = wave8 >= 8 && xrow < BM;
+    float cs = 0.0f, cd = 0.0f;
 
-    if (wave8 >= 4) {
+    if (wave8 >= 8) {
+        // ---- attention waves: after barrier c chunk c has landed for every wave; this lane's row of it joins the two chains
+        // in the MFMA's k order (c, d, t, q), done before barrier c + 1, after which the stage may be refilled.  All 16
+        // quads of the row go out right after the barrier (one exposed LDS round trip per chunk: the reads queue behind the
+        // computing waves' operand reads); u costs no memory access inside a chunk -- lane l holds u[64 c + l] in a VGPR (one
+        // coalesced load per vector, fetched a chunk ahead) and v_readlane broadcasts element k into the fma.
+        __builtin_amdgcn_s_setprio(3);
+        float usn = ux[lane], udn = ux[K + lane];
+        for (int c = 0; c < nchunks; ++c) {
+            const float usv = usn, udv = udn;
+            if (c + 1 < nchunks) {
+                usn = ux[((c + 1) << 6) + lane];
+                udn = ux[K + ((c + 1) << 6) + lane];
+            }
+            asm volatile("s_barrier" ::: "memory");                // barrier c
+            const float *st = gemm_lds + (c % NST) * STAGE + (xlive ? xrow : 0) * 64;
+            f32x4 aq[16];
+#pragma unroll
+            for (int kq = 0; kq < 16; ++kq) aq[kq] = *reinterpret_cast<const f32x4 *>(&st[4 * (kq ^ (xrow & 15))]);
+            if (!(NSC_BAND_ABL & 2)) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const int k = 16 * d + 4 * qq + t;
+                            const float su = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(usv), k));
+                            const float sd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(udv), k));
+                            cs = __builtin_fmaf(aq[4 * d + qq][t], su, cs);
+                            cd = __builtin_fmaf(aq[4 * d + qq][t], sd, cd);
+                        }
+            }
+        }
+        if (tid == 512) NSC_BAND_STAMP(7);
+    } else if (wave8 >= 4) {
         // ---- staging waves (as gemm_glds_kernel): piece j = tile rows 4 (wave + 4 j) .. + 3 of a 64-deep chunk
         const float *src[NPW];
         const int kq_base = lane & 15;
@@ -103,8 +194,7 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
                 gr = gr < 0 ? 0 : (gr < M ? gr : M - 1);            // target inside the graph has a source there
                 p = a.A + (long long)gr * K;
             } else {
-                const int Rb = R - BM;
-                p = (Rb < 64) ? a.B + (long long)(n0 + Rb) * K : a.Bx + (long long)(Rb - 64 < 1 ? Rb - 64 : 1) * K;
+                p = a.B + (long long)(n0 + R - BM) * K;
             }
             src[j] = p + 4 * kq;
         }
@@ -115,14 +205,21 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + (ch << 6)),
                                                  (__attribute__((address_space(3))) void *)(dst0 + j * 1024), 16, 0, 0);
         };
-        issue(0, 0);
-        if (NST == 3 && 1 < nchunks) issue(1, 1);
+        // NST stages: chunks 0 .. NST - 2 go out at once, chunk c + NST - 1 right after the barrier that retires chunk c - 1's
+        // stage; the wait for chunk c leaves the younger chunks' pieces in flight.  With NST = 4 and K = 256 (four chunks:
+        // the reference's hidden size) three of the four chunks are in flight from the start -- a 4-chunk K has no steady
+        // state, what bounds it is how soon the operand bytes arrive.
+#pragma unroll
+        for (int c0 = 0; c0 < NST - 1; ++c0)
+            if (c0 < nchunks) issue(c0, c0);
+        if (tid == 256) NSC_BAND_STAMP(5);
         for (int c = 0; c < nchunks; ++c) {
-            if (NST == 3 && c + 1 < nchunks) glds_wait_barrier<NPW>();
-            else glds_wait_barrier<0>();
+            const int issued = c + NST - 1 < nchunks ? c + NST - 1 : nchunks;       // chunks issued so far
+            band_wait_barrier<NPW>(issued - 1 - c);
             if (c + NST - 1 < nchunks) issue(c + NST - 1, (c + NST - 1) % NST);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 256) NSC_BAND_STAMP(6);
         if (tid < 256 + 64) {
             // BatchNorm (eval) of this tile's 64 columns folded to scale / shift by the staging waves, idle from their last
             // chunk on (gat_aggregate_kernel's expression: sc = invstd * w, shift = b - mean * sc)
@@ -142,69 +239,78 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
             const int idx = tid + 256 * c, lo = idx >> 3;
             const int i = own0 + lo;
             f32x4 e = {0.f, 0.f, 0.f, __int_as_float(-1)};
-            if (lo < OWN && i < M) e = a.ent[(long long)i * SLOTS + (idx & 7)];
+            if (lo < OWN && i < M && !(NSC_BAND_ABL & 4)) e = a.ent[(long long)i * SLOTS + (idx & 7)];
             pe[c] = e;
         }
-        const int boff = (BM + 16 * wave + r) * 64, xoff = (BM + 64 + r) * 64, aoff = r * 64;
-        const int x0 = aoff + (wave < ACC ? wave : 0) * 1024, x1 = aoff + (wave + 4 < ACC ? wave + 4 : 0) * 1024;
-        auto frags = [&](const float *st, int d, f32x4 &bv, f32x4 &bx, f32x4 (&av)[ACC], f32x4 (&ax)[2]) {
+        const int boff = (BM + 16 * wave + r) * 64, aoff = r * 64;
+        auto frags = [&](const float *st, int d, f32x4 &bv, f32x4 (&av)[ACC]) {
             const int slot = 4 * ((4 * d + q) ^ r);
             bv = *reinterpret_cast<const f32x4 *>(&st[boff + slot]);
 #pragma unroll
             for (int h = 0; h < ACC; ++h) av[h] = *reinterpret_cast<const f32x4 *>(&st[aoff + h * 1024 + slot]);
-            if (nA > 0) {
-                bx = *reinterpret_cast<const f32x4 *>(&st[xoff + slot]);
-                ax[0] = *reinterpret_cast<const f32x4 *>(&st[x0 + slot]);
-            }
-            if (ACC > 4 && nA > 1) ax[1] = *reinterpret_cast<const f32x4 *>(&st[x1 + slot]);
         };
-        auto mfmas = [&](const f32x4 &bv, const f32x4 &bx, const f32x4 (&av)[ACC], const f32x4 (&ax)[2], int t0, int t1) {
+        auto mfmas = [&](const f32x4 &bv, const f32x4 (&av)[ACC], int t0, int t1) {
 #pragma unroll
-            for (int t = t0; t < t1; ++t) {
+            for (int t = t0; t < t1; ++t)
 #pragma unroll
                 for (int h = 0; h < ACC; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[t], acc[h], 0, 0, 0);
-                if (nA > 0) accx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[0][t], bx[t], accx[0], 0, 0, 0);
-                if (ACC > 4 && nA > 1) accx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[1][t], bx[t], accx[1], 0, 0, 0);
-            }
         };
         asm volatile("s_barrier" ::: "memory");                    // barrier 0
-        f32x4 bv0, bv1, bx0 = zero, bx1 = zero, av0[ACC], av1[ACC], ax0[2] = {zero, zero}, ax1[2] = {zero, zero};
-        frags(gemm_lds, 0, bv0, bx0, av0, ax0);
+        if (tid == 0) NSC_BAND_STAMP(1);
+        f32x4 bv0, bv1, av0[ACC], av1[ACC];
+        frags(gemm_lds, 0, bv0, av0);
         for (int ch = 0; ch < nchunks; ++ch) {
             const float *st = gemm_lds + (ch % NST) * STAGE;
             const float *nx = gemm_lds + ((ch + 1) % NST) * STAGE;
             const bool last = ch + 1 == nchunks;
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(bv0, bx0, av0, ax0, 0, 2);
+            mfmas(bv0, av0, 0, 2);
             __builtin_amdgcn_sched_barrier(0);
-            frags(st, 1, bv1, bx1, av1, ax1);
+            frags(st, 1, bv1, av1);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(bv0, bx0, av0, ax0, 2, 4);
-            mfmas(bv1, bx1, av1, ax1, 0, 2);
+            mfmas(bv0, av0, 2, 4);
+            mfmas(bv1, av1, 0, 2);
             __builtin_amdgcn_sched_barrier(0);
-            frags(st, 2, bv0, bx0, av0, ax0);
+            frags(st, 2, bv0, av0);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(bv1, bx1, av1, ax1, 2, 4);
-            mfmas(bv0, bx0, av0, ax0, 0, 2);
+            mfmas(bv1, av1, 2, 4);
+            mfmas(bv0, av0, 0, 2);
             __builtin_amdgcn_sched_barrier(0);
-            frags(st, 3, bv1, bx1, av1, ax1);
+            frags(st, 3, bv1, av1);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(bv0, bx0, av0, ax0, 2, 4);
-            mfmas(bv1, bx1, av1, ax1, 0, 2);
+            mfmas(bv0, av0, 2, 4);
+            mfmas(bv1, av1, 0, 2);
             __builtin_amdgcn_sched_barrier(0);
             if (!last) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier ch + 1
-                frags(nx, 0, bv0, bx0, av0, ax0);
+                frags(nx, 0, bv0, av0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(bv1, bx1, av1, ax1, 2, 4);
+            mfmas(bv1, av1, 2, 4);
         }
+        if (tid == 0) NSC_BAND_STAMP(2);
+    }
+    // the residual quads of this thread's (target, column quad) pairs: requested here, a barrier pair and the softmax ahead
+    // of their use
+    const int grp = tid >> 4, s16 = tid & 15;
+    constexpr int NG = 640 / 16, NPASS = (OWN + NG - 1) / NG;
+    f32x4 rs[NPASS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int lo = pass * NG + grp, i = own0 + lo;
+        rs[pass] = zero;
+        if (a.resid && lo < OWN && i < M) rs[pass] = *reinterpret_cast<const f32x4 *>(a.resid + (long long)i * K + n0 + 4 * s16);
     }
     __syncthreads();                                               // nothing in flight, every operand read done
 
     // ---- h tile, attention columns, folded BatchNorm and the entries go to LDS
     float *Cs = gemm_lds;
-    if (wave8 >= 4) {
+    if (wave8 >= 8) {
+        if (xlive) {
+            Cs[O_AS + xrow] = cs;
+            Cs[O_AD + xrow] = cd;
+        }
+    } else if (wave8 >= 4) {
         if (tid < 256 + 64) {
             Cs[O_BN + tid - 256] = bn_pre[0];
             Cs[O_BN + 64 + tid - 256] = bn_pre[1];
@@ -216,15 +322,6 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)                      // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
                 Cs[(16 * h + 4 * q + reg) * LD + 16 * wave + r] = acc[h][reg];
-        if (r < 2) {                                               // column 0 of the attention block = a_src, column 1 = a_dst
-            float *dst = Cs + (r == 0 ? O_AS : O_AD);
-            if (nA > 0)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) dst[16 * wave + 4 * q + reg] = accx[0][reg];
-            if (ACC > 4 && nA > 1)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) dst[16 * (wave + 4) + 4 * q + reg] = accx[1][reg];
-        }
         const bool use_edge = a.v != nullptr;
         const float v0 = use_edge ? a.v[0] : 0.0f, v1 = use_edge ? a.v[1] : 0.0f;
 #pragma unroll
@@ -242,19 +339,20 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
     }
     __syncthreads();
 
-    // ---- attention + aggregation: a 16-lane group per target (4 targets per wave), lane s = entry slot s and column quad s
-    const int grp = tid >> 4, s16 = tid & 15;
+    if (tid == 0) NSC_BAND_STAMP(3);
+    // ---- attention + aggregation: a 16-lane group per target (4 targets per wave), lane s = entry slot s and column quad s.
+    // The softmaxes of all passes first, then the aggregations: independent latency chains (LDS gathers, cross-lane
+    // reductions) that the scheduler can interleave.
     const f32x4 bnsc = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 4 * s16]);
     const f32x4 bnsh = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 64 + 4 * s16]);
     const f32x4 bnbi = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 128 + 4 * s16]);
-    constexpr int NPASS = (OWN + 31) / 32;
+    float al_[NPASS];
+    int jl_[NPASS];
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-        const int lo = pass * 32 + grp, i = own0 + lo;
+        const int lo = pass * NG + grp, i = own0 + lo;
         const bool live = lo < OWN && i < M;                       // uniform over the 16-lane group
         const int lc = live ? lo : 0;
-        f32x4 rs = zero;
-        if (live && a.resid) rs = *reinterpret_cast<const f32x4 *>(a.resid + (long long)i * K + n0 + 4 * s16);
         f32x4 en = {__int_as_float(lc + HALO), 0.f, __int_as_float(-1), 0.f};
         if (s16 < SLOTS) en = *reinterpret_cast<const f32x4 *>(&Cs[O_EN + 4 * (lc * SLOTS + s16)]);
         const int jl = __float_as_int(en.x), eidx = __float_as_int(en.z);
@@ -269,11 +367,18 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
         const float den = group16_sum(p) + 1e-16f;                 // PyG softmax
         const float al = p / den;
         if (a.alpha_out && valid && live && n0 == 0) a.alpha_out[eidx] = al;
+        al_[pass] = al;
+        jl_[pass] = jl;
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int lo = pass * NG + grp, i = own0 + lo;
+        const bool live = lo < OWN && i < M;
         f32x4 o = zero;
 #pragma unroll
-        for (int t = 0; t < SLOTS; ++t) {                          // entries in CSR order, self loop last
-            const float at = __shfl(al, t, 16);
-            const int jt = __shfl(jl, t, 16);
+        for (int t = 0; t < ((NSC_BAND_ABL & 1) ? 1 : SLOTS); ++t) {   // entries in CSR order, self loop last
+            const float at = __shfl(al_[pass], t, 16);
+            const int jt = __shfl(jl_[pass], t, 16);
             const f32x4 gv = *reinterpret_cast<const f32x4 *>(&Cs[jt * LD + 4 * s16]);
             o.x = __builtin_fmaf(at, gv.x, o.x);
             o.y = __builtin_fmaf(at, gv.y, o.y);
@@ -285,15 +390,16 @@ __global__ __launch_bounds__(512) void gat_layer_banded_kernel(BandArgs a)
             float v = o[t] + bnbi[t];
             if (a.bn_w) v = v * bnsc[t] + bnsh[t];
             if (a.relu) v = fmaxf(v, 0.0f);
-            if (a.resid) v += rs[t];
+            if (a.resid) v += rs[pass][t];
             o[t] = v;
         }
         if (live) *reinterpret_cast<f32x4 *>(a.out + (long long)i * K + n0 + 4 * s16) = o;
     }
+    if (tid == 0) NSC_BAND_STAMP(4);
 }
 
-// Tile of the fused layer: 16 ACC rows computed, 16 ACC - 4 owned, 64 columns; the cost of a workgroup is the MFMA time of
-// its busiest computing wave (ACC main accumulators + its share of the ACC attention row blocks) + what a round costs besides.
+// Tile of the fused layer: 16 ACC rows computed, 16 ACC - 4 owned, 64 columns; the cost of a workgroup is the MFMA time of a
+// computing wave (ACC accumulators) + what a round costs besides.
 inline int band_pick_acc(int M, int H)
 {
     const long long nch = H / 64, ncb = H / 64;
@@ -303,16 +409,16 @@ inline int band_pick_acc(int M, int H)
         const int own = 16 * acc - 2 * NSC_BAND_HALO;
         const long long tiles = ncb * ((M + own - 1) / own);
         const long long rounds = (tiles + 255) / 256;
-        const long long cost = rounds * ((acc + (acc + 3) / 4) * nch * 512 + 3000);
+        const long long cost = rounds * (acc * nch * 512 + 3000);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = acc; }
     }
     return best;
 }
 
-template <int ACC>
+template <int ACC, int NST = 3>
 bool launch_banded_cfg(hipStream_t st, const BandArgs &a)
 {
-    constexpr unsigned lds = 3 * (16 * ACC + 80) * 256;
+    constexpr unsigned lds = NST * (16 * ACC + 64) * 256;
     static_assert(lds <= 160 * 1024, "LDS of a CU");
     if (lds > 64 * 1024) {                                         // per-device opt-in, as launch_glds_cfg
         static std::atomic<int> opted[16];
@@ -320,7 +426,7 @@ bool launch_banded_cfg(hipStream_t st, const BandArgs &a)
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
         int s = opted[dev].load(std::memory_order_acquire);
         if (s == 0) {
-            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gat_layer_banded_kernel<ACC, 3>),
+            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gat_layer_banded_kernel<ACC, NST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 2;
             opted[dev].store(s, std::memory_order_release);
         }
@@ -328,7 +434,7 @@ bool launch_banded_cfg(hipStream_t st, const BandArgs &a)
     }
     constexpr int own = 16 * ACC - 2 * NSC_BAND_HALO;
     const dim3 grid(a.H / 64, (a.M + own - 1) / own);
-    hipLaunchKernelGGL((gat_layer_banded_kernel<ACC, 3>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((gat_layer_banded_kernel<ACC, NST>), grid, dim3(640), lds, st, a, a.Bx);
     return true;
 }
 

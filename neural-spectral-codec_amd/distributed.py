@@ -407,10 +407,17 @@ class ShardedDescriptorPath:
                 and (hasattr(inner, "_live_tensors") or hasattr(inner, "parameters"))):     # (a plain callable runs eagerly)
             return self.gnn(self._graph)
         slot = self._k % self._PIPE_BUFFERS
+        folded = None
+        if hasattr(inner, "_model_struct"):
+            # the capture bakes in the folded attention vectors the model caches: make sure they exist for the current
+            # weights, and key on their generation -- an optimizer that writes through a multi-tensor kernel does not bump
+            # the parameters' version counters, GNNTrainer drops the cache after every step instead (a new generation)
+            inner._model_struct()
+            folded = inner._struct_cache[2]
         key = (x.data_ptr(), tuple(x.shape),
                tuple((t.data_ptr(), t._version) for t in (inner._live_tensors() if hasattr(inner, "_live_tensors")
                                                           else list(inner.parameters()) + list(inner.buffers()))),
-               getattr(inner, "coresident", False))
+               getattr(inner, "coresident", False), getattr(inner, "_fold_generation", 0))
         ent = self._gnn_graphs.get(slot)
         if ent is not None and ent[0] == key:
             ent[1].replay()
@@ -423,12 +430,22 @@ class ShardedDescriptorPath:
             with torch.cuda.graph(cg, stream=torch.cuda.current_stream(x.device), capture_error_mode="thread_local"):
                 out = self.gnn(self._graph)
             cg.replay()                                  # the capture itself ran nothing
-        except Exception:  # noqa: BLE001 -- whatever keeps a capture from closing: issue the forward eagerly from now on
+        except Exception as ex:  # noqa: BLE001 -- whatever keeps a capture from closing: issue the forward eagerly from now on
+            import logging
+            logging.getLogger(__name__).warning("hipGraph capture of the GNN forward failed (%s: %s); issuing it eagerly "
+                                                "from now on", type(ex).__name__, ex)
             self.gnn_graph = False
             self._gnn_graphs.clear()
             return self.gnn(self._graph)
-        self._gnn_graphs[slot] = (key, cg, out)
+        self._gnn_graphs[slot] = (key, cg, out, folded)      # (folded: kept alive as long as the capture that reads it)
         return out
+
+    def release(self):
+        """Drop the captured GNN forwards and the rotating buffers; the scratch buffers of the Python layer that captures
+        ran through are pinned until ``_lib.scratch.release()``."""
+        self._gnn_graphs.clear()
+        self._gnn_warm.clear()
+        self._desc_all.clear()
 
 
 def all_reduce_gradients(params, group=None, average: bool = False):

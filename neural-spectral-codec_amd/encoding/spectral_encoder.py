@@ -6,7 +6,6 @@ csrc/nsc_encoder.hip through the C ABI (include/nsc.h).  The module must live on
 
 Additive API (not in the reference): ``encode_points_batch`` for packed batches of clouds.
 """
-import threading
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -17,7 +16,6 @@ from .. import _lib
 from .range_image import RangeImageProjector, _as_points
 
 _LUT_CACHE = {}
-_WS_CACHE = {}
 
 
 def compute_bin_edges(alpha: torch.Tensor, n_bins: int, n_freqs: int, epsilon: float) -> torch.Tensor:
@@ -55,15 +53,9 @@ def _default_lut(device):
 def _workspace(device, nbytes):
     if nbytes == 0:
         return None
-    # one scratch buffer per (device, stream): launches issued on different streams may overlap (the pipelined step
-    # alternates its encoder launches over two streams), launches on one stream are ordered -- unless two host
-    # threads issue on it, hence the thread in the key
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
-    ws = _WS_CACHE.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _WS_CACHE[key] = ws
-    return ws
+    # one scratch buffer per (device, stream, host thread): launches issued on different streams may overlap (the
+    # pipelined step alternates its encoder launches over two streams); bounded, capture-safe (_lib.ScratchCache)
+    return _lib.scratch.get(device, nbytes, "enc")
 
 
 def _run_encode_clouds(pts, offsets, n_clouds, total_points, stride, p, lut, want_images=False,

@@ -9,28 +9,16 @@ The module must live on a HIP device; there is no CPU fallback.
 import ctypes as C
 from typing import Optional
 
-import threading
-
 import torch
 import torch.nn as nn
 
 from .. import _lib
 from .gat_conv import GATConv
 
-_WS = {}
-
-
 def _ws(device, nbytes, tag):
-    # one scratch buffer per (device, stream, use): work issued on different streams may overlap (pipelined steps,
-    # several ranks of a test sharing one process), work on one stream is ordered
-    # ... and per host thread: two threads issuing on one stream interleave their launches (a rehearsal of several ranks
-    # in one process; round 3: two ranks building their CSR in one shared scratch faulted the aggregate kernel)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), tag)
-    t = _WS.get(key)
-    if t is None or t.numel() < nbytes:
-        t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        _WS[key] = t
-    return t
+    # one scratch buffer per (device, stream, host thread, use), bounded and capture-safe: _lib.ScratchCache (round 3: two
+    # rank threads building their CSR in one shared scratch faulted the aggregate kernel; round 4: the dict only grew)
+    return _lib.scratch.get(device, nbytes, tag)
 
 
 class GraphCSR:
@@ -228,6 +216,7 @@ class SpectralGNN(nn.Module):
         state["_struct_cache"] = None
         state["_train_struct_cache"] = None
         state["_seed_dev"] = None
+        state["_fold_generation"] = 0
         state["_direct_grads"] = False
         return state
 
@@ -284,7 +273,8 @@ class SpectralGNN(nn.Module):
             st = L.nsc_gat_fold_weights(C.byref(m), _lib.ptr(folded), _lib.stream_ptr(dev))
         _lib.check(st, "nsc_gat_fold_weights")
         self._struct_cache = (key, m, folded)
-        return m
+        self._fold_generation = getattr(self, "_fold_generation", 0) + 1     # a captured forward bakes `folded` in: see
+        return m                                                              # ShardedDescriptorPath._enhance
 
     def _train_struct(self) -> _lib.GatModel:
         """NscGatModel for nsc_gat_forward_train / nsc_gat_backward: pointers into the live parameter storage, no folded

@@ -19,8 +19,6 @@ import torch.optim as optim
 
 from .. import _lib
 
-_WS = {}
-
 
 class _TripletFn(torch.autograd.Function):
     @staticmethod
@@ -91,7 +89,7 @@ class GNNTrainer:
     def __init__(self, model: nn.Module, device: str = 'cuda', learning_rate: float = 5e-4,
                  weight_decay: float = 1e-5, margin: float = 0.1, checkpoint_dir: Optional[str] = None,
                  log_interval: int = 10, use_multi_gpu: bool = True, patience: int = 10,
-                 batch_size: int = 1024, accumulation_steps: int = 4, use_graph: bool = True,
+                 batch_size: int = 1024, accumulation_steps: int = 4, use_graph: Optional[bool] = None,
                  direct_grads: bool = True):
         self.model = model.to(device)
         self.device = device
@@ -100,11 +98,17 @@ class GNNTrainer:
         self.optimizer = optim.Adam(model.parameters(), lr=learning_rate, weight_decay=weight_decay)  # :115-119
         self.criterion = TripletLoss(margin=margin)                                                   # :121
         self.batch_size, self.accumulation_steps = batch_size, accumulation_steps
-        # replay the per-batch step (forward + loss + backward) as a captured hipGraph from its second occurrence on
+        # replay the per-batch step (forward + loss + backward) as a captured hipGraph from its second occurrence on.
+        # None = decide per train_batches() call: on for one rank, OFF under an initialised process group of more than one
+        # rank -- RCCL's own threads issue HIP calls while a capture is open (ShardedDescriptorPath turns its GNN capture
+        # off beside RCCL for the same reason); True forces it (captures are opened in thread-local error mode).
         self.use_graph = use_graph
+        self.max_captures = 4                      # captured steps kept (LRU); each pins a hipGraph + its workspace pool
         # the backward adds into the existing .grad tensors itself instead of handing gradients to autograd's AccumulateGrad
         self.direct_grads = direct_grads
-        self._captured, self._seen_once, self._capture_failed = {}, set(), False
+        import collections
+        self._captured, self._seen_once, self._capture_failed = collections.OrderedDict(), set(), False
+        self._full_T = None                        # size of a full batch (slice) of the current train_batches() call
         # the reference creates 'checkpoints/' eagerly (:123-124); here the directory appears with the first save
         self.checkpoint_dir = Path(checkpoint_dir if checkpoint_dir is not None else 'checkpoints')
         self.log_interval = log_interval
@@ -278,19 +282,28 @@ class GNNTrainer:
         dropout seed (NscGatTrainCfg.seed_dev).  Gradients ACCUMULATE into the existing .grad tensors (the capture
         holds their addresses: zero_grad must keep them, set_to_none=False).  Returns the loss, or None when capture is
         not possible (then the caller runs the step eagerly)."""
-        if not self.use_graph or not torch.cuda.is_available() or torch.device(self.device).type != "cuda":
+        if not self._graph_enabled() or not torch.cuda.is_available() or torch.device(self.device).type != "cuda":
             return None
         inner = getattr(self.model, "gnn", self.model)
         params = [p for p in self.model.parameters() if p.requires_grad]
         T = int(len(bt))
-        key = (id(graph), graph.x.data_ptr(), graph.edge_index.data_ptr(), T, float(scale),
-               tuple(p.data_ptr() for p in params))
+        # only FULL batches are captured: the ragged last batch of an epoch has a different triplet count every epoch
+        # (and per rank), and each capture pins a hipGraph plus a private pool with the whole training workspace
+        if self._full_T is not None and T != self._full_T:
+            return None
+        ea = getattr(graph, "edge_attr", None)
+        use_edge = ea is not None and getattr(inner, "edge_dim", None) is not None
+        csr = inner._csr(graph, use_edge) if hasattr(inner, "_csr") else None     # the capture bakes its arrays in
+        key = (id(graph), graph.x.data_ptr(), graph.edge_index.data_ptr(), None if ea is None else ea.data_ptr(), id(csr),
+               T, float(scale), tuple(p.data_ptr() for p in params))
         ent = self._captured.get(key)
         dev = graph.x.device
         if ent is None:
             if self._capture_failed:
                 return None
             if key not in self._seen_once:
+                if len(self._seen_once) > 64:
+                    self._seen_once.clear()
                 self._seen_once.add(key)                    # first batch of this shape runs eagerly (lazy set-up, warm-up)
                 return None
             try:
@@ -303,17 +316,23 @@ class GNNTrainer:
                 inner._seed_dev = seed
                 torch.cuda.synchronize(dev)
                 cg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(cg):                  # records the launches; nothing runs until replay()
+                # thread-local error mode: HIP calls of OTHER threads (RCCL's proxy / watchdog) do not invalidate the capture
+                with torch.cuda.graph(cg, capture_error_mode="thread_local"):   # records the launches; nothing runs until replay()
                     loss = self._eager_step(graph, idx[0], idx[1], idx[2], scale)
-                ent = (cg, idx, seed, loss, [p.grad for p in params])
+                # the entry keeps what the capture baked in alive (CSR arrays, graph tensors): while it exists their ids
+                # and addresses in the key cannot be recycled
+                ent = (cg, idx, seed, loss, [p.grad for p in params], (csr, graph, ea))
                 self._captured[key] = ent
+                while len(self._captured) > self.max_captures:
+                    self._captured.popitem(last=False)      # least recently used capture: graph + pool are dropped
             except Exception as ex:  # noqa: BLE001 -- any capture problem: fall back to issuing the step eagerly
                 logging.warning(f"hipGraph capture of the training step failed ({type(ex).__name__}: {ex}); running eagerly")
                 self._capture_failed = True
                 return None
             finally:
                 inner._seed_dev = None
-        cg, idx, seed, loss, grads = ent
+        self._captured.move_to_end(key)
+        cg, idx, seed, loss, grads = ent[:5]
         for p, g in zip(params, grads):
             if p.grad is not g:                             # someone dropped / replaced the static gradient tensor
                 if p.grad is not None:
@@ -333,6 +352,17 @@ class GNNTrainer:
         seed.fill_(int(torch.randint(0, 2 ** 62, (1,)).item()) if float(getattr(inner, "dropout", 0.0)) > 0 else 0)
         cg.replay()                                         # (num_batches_tracked is incremented inside the capture)
         return loss.detach().clone()
+
+    def _graph_enabled(self) -> bool:
+        if self.use_graph is not None:
+            return bool(self.use_graph)
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def release(self):
+        """Drop the captured steps (hipGraphs + their workspace pools)."""
+        self._captured.clear()
+        self._seen_once.clear()
 
     def _ensure_flat_grads(self, params) -> None:
         """Gradient storage as views of ONE flat buffer (256-byte aligned slices): zeroing the gradients after an optimizer
@@ -377,11 +407,16 @@ class GNNTrainer:
         rank = dist.get_rank() if dist.is_initialized() else 0
         params = [p for p in self.model.parameters() if p.requires_grad]
         # gradients keep their storage across optimizer steps (a captured step holds their addresses)
-        if self.use_graph and torch.device(self.device).type == "cuda" and torch.cuda.is_available():
+        use_graph = self._graph_enabled()
+        if use_graph and torch.device(self.device).type == "cuda" and torch.cuda.is_available():
             self._ensure_flat_grads(params)
         self._zero_grads(params)
         trip_dev = None
-        if self.use_graph and len(triplets) and torch.device(self.device).type == "cuda" and torch.cuda.is_available():
+        self._full_T = None
+        if len(triplets):
+            flo, fhi = nd.shard_range(min(self.batch_size, len(triplets)), rank, world) if world > 1 else (0, min(self.batch_size, len(triplets)))
+            self._full_T = fhi - flo
+        if use_graph and len(triplets) and torch.device(self.device).type == "cuda" and torch.cuda.is_available():
             trip_dev = torch.from_numpy(np.ascontiguousarray(triplets.T, dtype=np.int64)).to(graph.x.device)   # (3, n), once
         for b in range(n_batches):
             b0 = b * self.batch_size

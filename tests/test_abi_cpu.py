@@ -22,7 +22,7 @@ def lib():
 
 
 def test_header_symbols_exported(lib):
-    from neural_spectral_codec_amd import _lib
+    from neural_spectral_codec_amd import _lib, build
     hdr = open(os.path.join(ROOT, "include", "nsc.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(nsc_[a-z0-9_]+)\s*\(", hdr))
@@ -30,6 +30,12 @@ def test_header_symbols_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/nsc.h but not exported"
     assert declared == set(_lib.SYMBOLS), "ctypes binding out of sync with include/nsc.h"
+    assert not any(n.startswith("nsc_debug") for n in declared), "diagnostics belong in include/nsc_debug.h"
+    dbg = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nsc_debug.h")).read(), flags=re.S)
+    assert set(re.findall(r"\b(nsc_[a-z0-9_]+)\s*\(", dbg)) == set(_lib.DEBUG_SYMBOLS)
+    assert hasattr(lib, "nsc_debug_point_bins")                       # parity triage: always built
+    dev = "-DNSC_DEV_TUNING" in open(build.FLAGS_FILE).read()
+    assert hasattr(lib, "nsc_debug_burn") == dev                      # the co-runner: development builds only
 
 
 def test_gemm_tile_choice(lib):
@@ -85,7 +91,8 @@ def test_argument_validation_without_gpu(lib):
     # the rows added around the path: shape checks answer without a device as well
     assert lib.nsc_gat_forward_ex(None, None, None, None, None, None, None, 0, 2, None) == -1     # unknown flag
     assert lib.nsc_gat_forward_ex(None, None, None, None, None, None, None, 0, 5, None) == -1     # LDS_TILED excludes CORESIDENT
-    assert lib.nsc_debug_burn(9, 1, 1, None, 0, None) == -1 and lib.nsc_debug_burn(0, 1, 1, None, 1 << 20, None) == -1
+    if hasattr(lib, "nsc_debug_burn"):                                # development builds only
+        assert lib.nsc_debug_burn(9, 1, 1, None, 0, None) == -1 and lib.nsc_debug_burn(0, 1, 1, None, 1 << 20, None) == -1
     assert lib.nsc_quantize_descriptors(None, 0, 800, 1e-8, None, None) == 0
     assert lib.nsc_quantize_descriptors(None, 3, 800, 1e-8, None, None) == -1
     assert lib.nsc_quantize_descriptors(None, 3, 5000, 1e-8, None, None) in (-1, -2)

@@ -379,3 +379,35 @@ def test_banded_attention_coefficients():
     assert torch.equal(out_a, out_b)
     for (ea, aa), (eb, ab) in zip(att_a, att_b):
         assert torch.equal(ea, eb) and torch.equal(aa, ab)
+
+
+def test_scratch_cache_is_bounded_and_never_replaces_a_buffer():
+    """_lib.ScratchCache (the Python layer's CSR / forward / encoder scratch): a larger request ADDS a buffer (a captured
+    hipGraph may replay the smaller one's address), keys of finished threads go first once the cap is reached, keys touched
+    during a stream capture are pinned until release()."""
+    import threading
+    from neural_spectral_codec_amd import _lib
+    c = _lib.ScratchCache(cap=4)
+    a = c.get("cuda:0", 1000, "x")
+    b = c.get("cuda:0", 5000, "x")
+    assert a.data_ptr() != b.data_ptr() and b.numel() >= 5000
+    assert c.get("cuda:0", 800, "x") is a and c.get("cuda:0", 4000, "x") is b and len(c) == 1
+
+    def worker():
+        c.get("cuda:0", 256, "y")
+    for _ in range(10):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+    assert len(c) <= 4 and c.get("cuda:0", 800, "x") is a          # the live thread's key survived the dead ones
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            pinned = c.get("cuda:0", 512, "captured")
+    for i in range(8):
+        c.get("cuda:0", 256, f"z{i}")
+    with torch.cuda.stream(s):
+        assert c.get("cuda:0", 512, "captured") is pinned
+    c.release()
+    assert len(c) == 0

@@ -455,6 +455,7 @@ def main():
     ap.add_argument("--gnn-nodes", type=int, default=0, help=argparse.SUPPRESS)      # DIAGNOSTIC: GNN over the first n keyframes only
     ap.add_argument("--gnn-burn", default="", help=argparse.SUPPRESS)                # DIAGNOSTIC: MODE:WGS:PER_WAVE[:LAUNCHES] synthetic co-runner (nsc_debug_burn) in place of the GNN
     ap.add_argument("--no-gnn", action="store_true", help=argparse.SUPPRESS)         # DIAGNOSTIC (not the metric): identity in place of the GNN
+    ap.add_argument("--pipe-buffers", type=int, default=0, help=argparse.SUPPRESS)   # descriptor buffers in rotation (0 = the path's default)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -491,6 +492,8 @@ def main():
     from neural_spectral_codec_amd.encoding import SpectralEncoder
     from neural_spectral_codec_amd.gnn.model import create_spectral_gnn
 
+    if args.pipe_buffers > 0:
+        nd.ShardedDescriptorPath._PIPE_BUFFERS = args.pipe_buffers
     n_local = args.clouds
     n_total = n_local * world
     enc = SpectralEncoder(n_elevation=16, n_azimuth=360, n_bins=50, alpha=2.0,
@@ -774,7 +777,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,
             "clocks_mid_run": clocks_busy,
-            "stream_debug": {"hw_queue_classes": getattr(path, "queue_classes", None),
+            "stream_debug": {"hw_queue_classes": getattr(path, "queue_classes", None), "pipe_buffers": nd.ShardedDescriptorPath._PIPE_BUFFERS,
                              "encoder_waits_for_gnn": getattr(path, "gnn_waits", None),
                              "launch_end_intervals_us": [round(ev[k][1].elapsed_time(ev[k + 1][1]) * 1e3, 1)
                                                          for k in range(min(args.steps, 64) - 1)],

@@ -28,12 +28,12 @@ def _free_port():
     return p
 
 
-def _run_world(tmp, tag, world, mode, n_total, timeout=420):
+def _run_world(tmp, tag, world, mode, n_total, timeout=420, points=6000):
     port = _free_port()
     outs = [os.path.join(tmp, f"{tag}_r{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, WORKER, "--rank", str(r), "--world", str(world), "--port", str(port),
-                               "--mode", mode, "--n-total", str(n_total), "--out", outs[r]],
+                               "--mode", mode, "--n-total", str(n_total), "--points", str(points), "--out", outs[r]],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     try:
@@ -257,3 +257,28 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["calibration"] is not None and line["allgather"]["alone_ms"] > 0 and line["allgather"]["events"] == 6
     assert abs(line["value"] - 2 * 96 * 6 / (line["ms_per_step"] * 6e-3)) <= 1e-6 * line["value"]
     assert "REHEARSAL" in line["data"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["serial", "pipelined"])
+def test_equal_shards_at_the_bench_shape_through_hip_kernels(tmp_path, mode):
+    """The branch ``bench.py --gpus N`` takes: EQUAL shards of 1 024 keyframes per rank (world 4 here, child processes over
+    gloo, 2 000-point clouds).  One stream ("serial"): the overlapped two-phase exchange -- boundary rows first, the big
+    all-gather asynchronous under the GNN forward (``overlap`` must be on); pipelined: ONE all-gather per step into the
+    rotating gathered-matrix slots.  Every rank's gathered matrix, owned rows (also those kept from two steps before) and
+    merged retrieval result equal the single process, bit for bit."""
+    world, n_total, pts = 4, 4096, 2000
+    ref = _run_world(str(tmp_path), "single", 1, mode, n_total, points=pts, timeout=600)[0]
+    res = _run_world(str(tmp_path), f"w{world}_{mode}", world, mode, n_total, points=pts, timeout=600)
+    assert np.isfinite(ref["emb"]).all() and np.abs(ref["desc_all"].sum(1) - 1).max() < 1e-5
+    for r, z in enumerate(res):
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert hi - lo == 1024
+        assert int(z["overlap"]) == (1 if mode == "serial" else 0)        # (pipeline mode hides the whole exchange instead)
+        assert np.array_equal(z["desc_all"].view(np.uint32), ref["desc_all"].view(np.uint32)), f"rank {r} gathered matrix"
+        assert np.array_equal(z["emb"].view(np.uint32), ref["emb"][lo:hi].view(np.uint32)), f"rank {r} owned rows"
+        if mode == "pipelined":
+            assert np.array_equal(z["desc_all_kept"].view(np.uint32), ref["desc_all"].view(np.uint32))
+            assert np.array_equal(z["emb_kept"].view(np.uint32), ref["emb"][lo:hi].view(np.uint32))
+        assert np.array_equal(z["retr_idx"], ref["retr_idx"]) and np.array_equal(z["retr_val"].view(np.uint32),
+                                                                                  ref["retr_val"].view(np.uint32))

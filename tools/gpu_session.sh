@@ -7,6 +7,7 @@
 #   one NAME [bench args]    one bench.py invocation -> $O/NAME.json, one summary line
 #   ab CFG...                development build, interleaved A/B of encoder variants (tools/ab_enc.py); AB_ORDER honoured
 #   gat                      GAT parity tests, forward timings, per-kernel trace at N = 4541 / 1024
+#   build [DEFINE ...]       rebuild csrc/libnsc_hip.so with -DDEFINE ... (no argument: the product build)
 #   py SCRIPT [args]         python SCRIPT args  -> $O/<script>.log
 #   prof NAME CMD...         rocprofv3 --kernel-trace --stats -d $O/NAME -- CMD...
 # Every step's status is propagated, and a "Memory access fault" / core dump anywhere in the session's logs makes the
@@ -58,6 +59,10 @@ run_step() {
             rocprofv3 --kernel-trace --stats --output-format csv -d $O/gat_trace_$n -- python3 $R/tools/gat_workload.py $n 50 > $O/gat_trace_$n.log 2>&1 || return 1
         done
         python3 $R/tools/summarize_gat_trace.py $O ;;
+    build)
+        # build [DEFINE ...]: rebuild the library with -DDEFINE ... (A/B builds; `build` alone restores the product build)
+        cd $R; NSC_DEV_DEFINES="$*" python neural-spectral-codec_amd/build.py > $O/build_$(echo "$*" | tr -c 'A-Za-z0-9\n' '_').log 2>&1; rc=$?
+        echo "build [$*] rc=$rc"; return $rc ;;
     py)
         local script=$1; shift; cd $R
         local log=$O/$(basename $script .py).log

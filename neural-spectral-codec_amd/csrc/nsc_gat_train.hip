@@ -299,12 +299,130 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__r
     }
 }
 
+// A second, one-component sum that rides along a final pass (round 4): out[c] (+)= sum_r part[r][c], float64 partials of
+// ANOTHER matrix written by an earlier kernel of the stream (the conv / input bias gradient, whose pass 1 is fused into
+// bn_apply_colsum_kernel: one launch and one read of the (N, H) matrix less per BatchNorm).
+struct ColExtra {
+    const double *part;          // (R, C) or null
+    int R, acc;
+    float *out;
+};
+
 // Pass 2: the R partial rows of a 64-column block, summed in fixed order (deterministic), then the finish (ColFinal).
-__global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C, ColFinal f)
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C, ColFinal f,
+                                                              ColExtra x)
 {
     __shared__ double sa[256], sb[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    colreduce_finish(part, R, C, blockIdx.x * 64 + cx, cx, ry, sa, sb, f);
+    const int c = blockIdx.x * 64 + cx;
+    if (part) colreduce_finish(part, R, C, c, cx, ry, sa, sb, f);
+    if (x.part) {
+        __syncthreads();                                   // (sa is reused; the threads that left colreduce_finish early are back)
+        double a = 0.0;
+        if (c < C)
+            for (int r = ry; r < x.R; r += 4) a += x.part[(long long)r * C + c];
+        sa[threadIdx.x] = a;
+        __syncthreads();
+        if (ry == 0 && c < C) {
+            a = (sa[cx] + sa[64 + cx]) + (sa[128 + cx] + sa[192 + cx]);
+            x.out[c] = x.acc ? x.out[c] + (float)a : (float)a;
+        }
+    }
+}
+
+// BatchNorm backward, pass 1, with the activation backward fused in (round 4: bn_act_bwd_dv_kernel + colreduce_partial_kernel
+// were two launches and two passes over the (N, C) matrix):  dV = dH * dropmask * relu'(v) is computed on the fly (v from z
+// and the batch statistics, as the forward did), STORED for the apply pass, and reduced:
+//   s1[c] = sum_n dV[n][c],  s2[c] = sum_n dV[n][c] * xhat[n][c],  xhat = (z - mean) * invstd
+// Same expressions, same order of additions as the two kernels it replaces.
+__global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(const float *__restrict__ dh, const float *__restrict__ z,
+                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            int relu, float p, SeedRef seed, unsigned stream, int N, int C,
+                                                            int rows_per_block, float *__restrict__ dv,
+                                                            double *__restrict__ part)
+{
+    __shared__ double sa[256], sb[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const float m = mean[c], s = invstd[c], ga = gamma[c], be = beta[c];
+        const unsigned long long sd = p > 0.0f ? seed.get() : 0ull;
+        auto step = [&](int n, float dhv, float zv) {
+            const long long i = (long long)n * C + c;
+            float g = dhv * keep_scale(p, sd, stream, (unsigned long long)i);
+            if (relu) {
+                const float v = (zv - m) * s * ga + be;
+                if (!(v > 0.0f)) g = 0.0f;
+            }
+            dv[i] = g;
+            a += (double)g;
+            b += (double)g * (double)((zv - m) * s);
+        };
+        int n = n0 + ry;
+        for (; n + 28 < n1; n += 32) {
+            float dv8[8], zv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                dv8[u] = dh[(long long)(n + 4 * u) * C + c];
+                zv8[u] = z[(long long)(n + 4 * u) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(n + 4 * u, dv8[u], zv8[u]);
+        }
+        for (; n < n1; n += 4) step(n, dh[(long long)n * C + c], z[(long long)n * C + c]);
+    }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        a = sa[cx] + sa[64 + cx] + sa[128 + cx] + sa[192 + cx];
+        b = sb[cx] + sb[64 + cx] + sb[128 + cx] + sb[192 + cx];
+        part[((long long)blockIdx.y * C + c) * 2] = a;
+        part[((long long)blockIdx.y * C + c) * 2 + 1] = b;
+    }
+}
+
+// BatchNorm backward, apply pass, with pass 1 of the bias gradient fused in (round 4: bn_bwd_apply_kernel +
+// colreduce_partial_kernel):  dZ = gamma * invstd * (dV - s1 / N - xhat * s2 / N)  in place, and the float64 partials of
+// sum_n dZ[n][c] (the gradient of the bias in front of this BatchNorm; a final pass adds them up: ColExtra).
+__global__ __launch_bounds__(256) void bn_apply_colsum_kernel(float *__restrict__ dv, const float *__restrict__ z,
+                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                              const float *__restrict__ gamma, const float *__restrict__ s1,
+                                                              const float *__restrict__ s2, int N, int C, int rows_per_block,
+                                                              double *__restrict__ part)
+{
+    __shared__ double sa[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+    double a = 0.0;
+    if (c < C) {
+        const float m = mean[c], s = invstd[c], ga = gamma[c], t1 = s1[c], t2 = s2[c];
+        const float invn = 1.0f / (float)N;
+        auto step = [&](int n, float dvv, float zv) {
+            const float xhat = (zv - m) * s;
+            const float dz = ga * s * (dvv - t1 * invn - xhat * t2 * invn);
+            dv[(long long)n * C + c] = dz;
+            a += (double)dz;
+        };
+        int n = n0 + ry;
+        for (; n + 28 < n1; n += 32) {
+            float dv8[8], zv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                dv8[u] = dv[(long long)(n + 4 * u) * C + c];
+                zv8[u] = z[(long long)(n + 4 * u) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(n + 4 * u, dv8[u], zv8[u]);
+        }
+        for (; n < n1; n += 4) step(n, dv[(long long)n * C + c], z[(long long)n * C + c]);
+    }
+    sa[threadIdx.x] = a;
+    __syncthreads();
+    if (ry == 0 && c < C) part[(long long)blockIdx.y * C + c] = sa[cx] + sa[64 + cx] + sa[128 + cx] + sa[192 + cx];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,45 +444,6 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ z
     v *= keep_scale(p, seed.get(), stream, (unsigned long long)i);
     if (resid) v += resid[i];
     out[i] = v;
-}
-
-// dV = dH * dropmask * relu'(v),  v recomputed from z and the batch statistics
-__global__ __launch_bounds__(256) void bn_act_bwd_dv_kernel(const float *__restrict__ dh,
-                                                            const float *__restrict__ z,
-                                                            const float *__restrict__ mean,
-                                                            const float *__restrict__ invstd,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, int relu, float p,
-                                                            SeedRef seed, unsigned stream,
-                                                            long long total, int C, float *__restrict__ dv)
-{
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    float g = dh[i] * keep_scale(p, seed.get(), stream, (unsigned long long)i);
-    if (relu) {
-        const float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-        if (!(v > 0.0f)) g = 0.0f;
-    }
-    dv[i] = g;
-}
-
-// dZ = gamma*invstd*(dV - s1/N - xhat*s2/N)   (s1 = sum dV, s2 = sum dV*xhat per column)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ dv,
-                                                           const float *__restrict__ z,
-                                                           const float *__restrict__ mean,
-                                                           const float *__restrict__ invstd,
-                                                           const float *__restrict__ gamma,
-                                                           const float *__restrict__ s1,
-                                                           const float *__restrict__ s2, long long total, int C,
-                                                           int N, float *__restrict__ dz)
-{
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const float xhat = (z[i] - mean[c]) * invstd[c];
-    const float invn = 1.0f / (float)N;
-    dz[i] = gamma[c] * invstd[c] * (dv[i] - s1[c] * invn - xhat * s2[c] * invn);
 }
 
 __global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b,
@@ -916,7 +995,7 @@ struct TrainWs {
     // saved by the forward
     size_t z0, mean0, invstd0, h, g, a_src, a_dst, alpha, y, mean, invstd, vvec;
     // backward scratch
-    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, total;
+    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, colpart2, total;
     size_t nh, nn, hh, nz;
 };
 
@@ -953,6 +1032,7 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
     w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);
     w.colpart = o; o += align256((size_t)COLRED_MAXR * std::max(std::max(H, m->out_dim), m->in_dim) * 2 * 8);
+    w.colpart2 = o; o += align256((size_t)COLRED_MAXR * H * 8);      // partials of the bias gradient (bn_apply_colsum_kernel)
     w.total = o;
     return w;
 }
@@ -1012,18 +1092,47 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
     }
 }
 
-void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
-               int N, int C, double *part, int mode, float eps, float momentum, float *out_a,
-               float *out_b, float *run_mean, float *run_var, int acc_a = 0, int acc_b = 0, float *copy_a = nullptr,
-               float *copy_b = nullptr, int acc_copy = 0, const float *w2 = nullptr)
+inline int colred_rows(int N)
 {
     int R = (N + 63) / 64;
     if (R > COLRED_MAXR) R = COLRED_MAXR;
-    if (R < 1) R = 1;
+    return R < 1 ? 1 : R;
+}
+
+void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
+               int N, int C, double *part, int mode, float eps, float momentum, float *out_a,
+               float *out_b, float *run_mean, float *run_var, int acc_a = 0, int acc_b = 0, float *copy_a = nullptr,
+               float *copy_b = nullptr, int acc_copy = 0, const float *w2 = nullptr, ColExtra extra = ColExtra{nullptr, 0, 0, nullptr})
+{
+    const int R = colred_rows(N);
     const int rows = (N + R - 1) / R;
     const ColFinal f = {mode, N, eps, momentum, out_a, out_b, run_mean, run_var, acc_a, acc_b, copy_a, copy_b, acc_copy};
     hipLaunchKernelGGL(colreduce_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, P, w, Q, qm, qs, N, C, rows, part, w2);
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f, extra);
+}
+
+// BatchNorm backward of one layer in three launches (round 3: five): dV + its two column sums; their final (which also stores
+// the BatchNorm parameter gradients); dZ in place + the partials of its column sum, returned as the ColExtra the caller hands
+// to its next final pass (or to bias_final).
+ColExtra bn_backward(hipStream_t st, const float *dh, const float *z, const float *mean, const float *invstd, const float *gamma,
+                     const float *beta, int relu, float p, SeedRef seed, unsigned stream, int N, int C, float *dv, float *s1,
+                     float *s2, float *g_bn_b, float *g_bn_w, int acc, double *part, double *part2, float *g_bias)
+{
+    const int R = colred_rows(N);
+    const int rows = (N + R - 1) / R;
+    const dim3 grid((C + 63) / 64, R);
+    hipLaunchKernelGGL(bn_bwd_colsum_kernel, grid, dim3(256), 0, st, dh, z, mean, invstd, gamma, beta, relu, p, seed, stream, N, C,
+                       rows, dv, part);
+    const ColFinal f = {0, N, 0.f, 0.f, s1, s2, nullptr, nullptr, 0, 0, g_bn_b, g_bn_w, acc};
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f, ColExtra{nullptr, 0, 0, nullptr});
+    hipLaunchKernelGGL(bn_apply_colsum_kernel, grid, dim3(256), 0, st, dv, z, mean, invstd, gamma, s1, s2, N, C, rows, part2);
+    return ColExtra{part2, R, acc, g_bias};
+}
+
+void bias_final(hipStream_t st, int C, const ColExtra &x)
+{
+    const ColFinal none = {0, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, static_cast<const double *>(nullptr), 0, C, none, x);
 }
 
 inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
@@ -1129,10 +1238,20 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
                            act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, resid, NH, H, hout);
     }
     // output_proj + input residual                                             model.py:144-151
-    gemm<false, false>(st, F(w.h + w.nh * L), H, m->out_w, H, N, m->out_dim, H, out, m->out_dim, m->out_b, 0, 1, nullptr);
+    bool fused_res = false;
+    if (m->residual && m->in_dim == m->out_dim) {
+        // (acc + bias) + x in the GEMM's epilogue: the order of the GEMM followed by out += x, one launch and one pass over the
+        // (N, 800) output less (round 4)
+        GemmEpi ep = {};
+        ep.bias = m->out_b;
+        ep.resid = x; ep.ldr = m->in_dim;
+        fused_res = launch_glds<2>(st, F(w.h + w.nh * L), H, m->out_w, H, nullptr, N, m->out_dim, m->out_dim, H, out, m->out_dim, ep);
+    }
+    if (!fused_res)
+        gemm<false, false>(st, F(w.h + w.nh * L), H, m->out_w, H, N, m->out_dim, H, out, m->out_dim, m->out_b, 0, 1, nullptr);
     if (m->residual && m->in_dim == m->out_dim) {
         const long long tot = (long long)N * m->out_dim;
-        hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(tot)), dim3(256), 0, st, out, x, tot);
+        if (!fused_res) hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(tot)), dim3(256), 0, st, out, x, tot);
     } else if (m->residual) {                                                  // out += residual_proj(x)  model.py:147-149
         gemm<false, false>(st, x, m->in_dim, m->res_w, m->in_dim, N, m->out_dim, m->in_dim, out, m->out_dim, m->res_b, 1, 1,
                            nullptr);
@@ -1155,6 +1274,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     char *b = static_cast<char *>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
+    double *colpart2 = reinterpret_cast<double *>(b + w.colpart2);
     float *slabs = F(w.slabs);
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
@@ -1196,15 +1316,13 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         float *dv = F(w.dv), *dG = F(w.dg), *s1 = F(w.s1), *s2 = F(w.s2);
         const int act = (l < L - 1);
         const bool has_res = (m->residual && l > 0 && l < L - 1);
-        // h_{l+1} = drop(relu(bn(y))) [+ h_l]  ->  dV, BatchNorm backward -> dY (in place in dv)
-        hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
-                           act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, NH, H, dv);
-        // s1 / s2 feed bn_bwd_apply AND are the BatchNorm parameter gradients: the reduction's finish stores both
-        colreduce(st, dv, nullptr, y, mean, invstd, N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr, 0, 0, Gl.bn_b, Gl.bn_w, acc);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, y, mean, invstd, Ly.bn_w, s1, s2, NH, H, N, dv);
+        // h_{l+1} = drop(relu(bn(y))) [+ h_l]  ->  dV, BatchNorm backward -> dY (in place in dv).  s1 / s2 feed the apply
+        // pass AND are the BatchNorm parameter gradients (the final stores both); the conv bias gradient = column sums of dY:
+        // its partials come out of the apply pass, its final rides along the attention-vector reduction below
+        const ColExtra bias_x = bn_backward(st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act, act ? cfg->dropout_p : 0.0f,
+                                            SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l,
+                                            N, H, dv, s1, s2, Gl.bn_b, Gl.bn_w, acc, colpart, colpart2, Gl.bias);
         float *dY = dv;
-        // conv bias
-        colreduce(st, dY, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.bias, nullptr, nullptr, nullptr, acc);
         // attention backward
         AttBwdA A;
         A.row_ptr = g->row_ptr; A.src = g->src; A.eid = g->eid;
@@ -1233,7 +1351,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         }
         // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
         colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, Gl.att_dst, nullptr, nullptr, acc,
-                  acc, nullptr, nullptr, 0, F(w.da_dst));
+                  acc, nullptr, nullptr, 0, F(w.da_dst), bias_x);
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
             if (use_edge) {
                 hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,
@@ -1255,13 +1373,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     }
     // h_0 = relu(bn(z0)),  z0 = x W_in^T + b_in
     float *dv = F(w.dv), *s1 = F(w.s1), *s2 = F(w.s2);
-    hipLaunchKernelGGL(bn_act_bwd_dv_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
-                       m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, NH, H, dv);
-    colreduce(st, dv, nullptr, F(w.z0), F(w.mean0), F(w.invstd0), N, H, colpart, 0, 0.f, 0.f, s1, s2, nullptr, nullptr, 0, 0,
-              gr->in_bn_b, gr->in_bn_w, acc);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(NH)), dim3(256), 0, st, dv, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, s1, s2,
-                       NH, H, N, dv);
-    colreduce(st, dv, nullptr, nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, gr->in_b, nullptr, nullptr, nullptr, acc);
+    bias_final(st, H, bn_backward(st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u,
+                                  N, H, dv, s1, s2, gr->in_bn_b, gr->in_bn_w, acc, colpart, colpart2, gr->in_b));
     gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, acc, splits, slabs);
     if (gr->x) {   // + dZ0 W_in
         gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, slabs);

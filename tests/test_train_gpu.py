@@ -535,3 +535,36 @@ def test_captured_training_step_matches_eager():
     tr2 = GNNTrainer(m2, device="cuda", learning_rate=5e-4, batch_size=256, accumulation_steps=1)
     ls = [tr2.train_batches(g2, np.concatenate([trip2] * 2)) for _ in range(8)]
     assert tr2._captured and ls[-1] < ls[0]
+
+
+@pytest.mark.parametrize("n,dropout", [(700, 0.0), (1500, 0.1)])
+def test_in_kernel_gradient_accumulation_is_bit_exact(n, dropout):
+    """A parity bar that does not lean on the triplet scatter's float atomics: with a deterministic upstream gradient
+    (loss = <emb, W>) every kernel of the backward is deterministic, so
+      * two runs of the same backward agree bit for bit,
+      * NscGatTrainCfg.accumulate_grads = 1 into ZEROED gradient buffers equals accumulate_grads = 0 bit for bit (0 + g = g:
+        the split-K slab sums, the column-reduction finishes and the fused bias partials all add their finished float to what
+        the buffer holds),
+      * a second accumulating backward doubles every gradient exactly (g + g)."""
+    grads = []
+    for mode in ("autograd", "autograd", "direct", "direct_twice"):
+        m, g, _ = _setup(n, 2, dropout=dropout, seed=5)
+        m.train()
+        inner = m.gnn
+        torch.manual_seed(3)                                       # the dropout seed is drawn from torch's CPU generator
+        W = torch.linspace(-1.0, 1.0, n * 800, device="cuda").reshape(n, 800)
+        if mode != "autograd":
+            for p in m.parameters():
+                p.grad = torch.zeros_like(p)
+            inner._direct_grads = True
+        for rep in range(2 if mode == "direct_twice" else 1):
+            torch.manual_seed(3)
+            (m(g) * W).sum().backward()
+        inner._direct_grads = False
+        grads.append({k: v.grad.detach().clone() for k, v in inner.named_parameters()})
+    a0, a1, d, d2 = grads
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), f"{k}: the backward is not deterministic"
+        assert torch.equal(a0[k], d[k]), f"{k}: accumulate_grads = 1 into zeros differs from accumulate_grads = 0"
+        assert torch.equal(d2[k], d[k] + d[k]), f"{k}: a second accumulating backward does not double the gradient"
+        assert torch.isfinite(a0[k]).all()

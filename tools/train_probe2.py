@@ -21,7 +21,7 @@ for n in (1024, 4541):
     trip = rng.integers(0, n, (4096, 3))
     tr.train_batches(g, trip); tr.train_batches(g, trip)
     assert tr._captured and not tr._capture_failed
-    (cg, idx, seed, loss, grads), = tr._captured.values()
+    cg, idx, seed, loss, grads = next(iter(tr._captured.values()))[:5]
     dev_trip = torch.from_numpy(np.ascontiguousarray(trip.T)).cuda()
     print(f"N={n}: replay only {T(cg.replay, 40):.3f} ms; ", end="")
     def upd():

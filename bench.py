@@ -275,14 +275,14 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
         inner.coresident = was
         tf = GAT_FLOP_PER_NODE * 4541 / (gat[4541] * 1e-6) / 1e12
         out["roofline_gat"] = {
-            "bound": "mfma_f32", "kernel": "gemm_glds_kernel (800->256, 3 x 256->256, 256->800) + gat_aggregate_kernel",
+            "bound": "mfma_f32", "kernel": "gemm_glds_kernel (800->256, 256->800) + 3 x gat_layer_banded_kernel (lin 256->256 + softmax + aggregation + BatchNorm in one launch per layer)",
             "workload": "BASELINE.json configs[2]: 4541 keyframes, 18158 temporal edges, edge_dim=2, eval mode, one GPU",
             "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
             "flop_per_forward": GAT_FLOP_PER_NODE * 4541, "forward_us": gat[4541],
             "forward_us_at_step_size": gat[n_local], "forward_us_as_hipgraph": gat_graph.get(4541),
             "forward_us_at_step_size_as_hipgraph": gat_graph.get(n_local), "traffic": None,
-            "note": "whole forward (8 launches) by HIP events; per-kernel durations and the MFMA counters "
-                    "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32) are in profiles/r03_gat_n4541_*",
+            "note": "whole forward (5 launches) by HIP events; per-kernel durations and the MFMA counters "
+                    "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32) are in profiles/r04_gat_n4541_*",
         }
         # the three point orders interleaved, so that clock drift between "then" and "now" cannot pass for an effect of the
         # order: 5 rounds of 8 launches each, median per order
@@ -308,10 +308,57 @@ def measure_extras(enc, model, dev, n_local, scratch, uniform):
         try:
             out["incl_h2d"] = measure_h2d(enc, model, dev, n_local, uniform)
             out["latency_us"] = measure_latencies(enc, model, dev)
+            out["roofline_train"] = measure_train(dev)
         except Exception as ex:  # noqa: BLE001 -- side measurements must not take the bench down
             print(f"[bench] H2D / latency extras not measured ({type(ex).__name__}: {ex})", file=sys.stderr)
     gc.enable()
     return out
+
+
+def measure_train(dev):
+    """BASELINE configs[4]'s per-batch step (reference src/gnn/trainer.py:186-231: full-graph forward in train mode +
+    TripletLoss over 1 024 triplets + backward) on the KITTI-00-shaped graph, replayed as the captured hipGraph GNNTrainer
+    runs it as; MFMA work = forward + two backward products per forward product = 3 x 5.51 GFLOP."""
+    from neural_spectral_codec_amd.gnn.model import create_spectral_gnn
+    from neural_spectral_codec_amd.gnn.trainer import GNNTrainer
+    from neural_spectral_codec_amd.keyframe import graph_manager as gm
+    n = 4541
+    with torch.enable_grad():
+        torch.manual_seed(0)
+        m = create_spectral_gnn(edge_dim=2, dropout=0.1)
+        g = gm.synthetic_chain_graph(n, device=dev, seed=1)
+        tr = GNNTrainer(m, device=str(dev), batch_size=1024, accumulation_steps=4, use_graph=True)
+        trip = np.random.default_rng(0).integers(0, n, (4096, 3))
+        for _ in range(3):
+            tr.train_batches(g, trip)
+        if not tr._captured:
+            raise RuntimeError("the training step was not captured")
+        cg = next(iter(tr._captured.values()))[0]
+        best = None
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                cg.replay()
+            b.record()
+            torch.cuda.synchronize(dev)
+            us = a.elapsed_time(b) / 20 * 1e3
+            best = us if best is None else min(best, us)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.train_batches(g, trip)
+        torch.cuda.synchronize(dev)
+        per_batch_ms = (time.perf_counter() - t0) / 5 / 4 * 1e3
+        tr.release()
+    flop = 3.0 * GAT_FLOP_PER_NODE * n
+    tf = flop / (best * 1e-6) / 1e12
+    return {"bound": "mfma_f32", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+            "step_us": best, "flop_per_step": flop, "per_batch_incl_adam_ms": per_batch_ms,
+            "workload": "BASELINE.json configs[4] shape on one GPU: 4541 keyframes, 1024 mined-triplet batch, hidden 256, margin 0.1, "
+                        "dropout 0.1: forward (train mode) + TripletLoss + backward as ONE captured hipGraph replay "
+                        "(~90 kernels: the step is launch- and latency-bound, not MFMA-bound); per_batch_incl_adam_ms = "
+                        "GNNTrainer.train_batches with its optimizer step every 4 batches"}
 
 
 def measure_h2d(enc, model, dev, n_local, uniform):
@@ -830,6 +877,8 @@ def main():
                 line["incl_h2d"] = extras["incl_h2d"]
             if "latency_us" in extras:
                 line["latency_us"] = extras["latency_us"]
+            if "roofline_train" in extras:
+                line["roofline_train"] = extras["roofline_train"]
             # the headline workload is the uniform-order batch; the same kernel alone on sensor-ordered clouds:
             line["roofline"]["standalone_launch_ms_by_input_order"] = dict(extras["encoder_input_order_ms"])
         if world == 1 and not args.no_cpu_baseline:

@@ -3,7 +3,7 @@
 # workload, PMC traffic of the encoder kernel (separate passes), the GAT half (trace + MFMA counters), the training step.
 # Outputs land in gpurun_out/<TAG>_profiles/; tools/publish_bench_profiles.sh copies the summaries into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/${TAG}_profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

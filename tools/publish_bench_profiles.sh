@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the bench-side records of tools/collect_profiles.sh into profiles/ and write the summaries.
 # usage: tools/publish_bench_profiles.sh gpurun_out/<tag>_profiles r03
-S=$1; T=${2:-r03}
+S=$1; T=${2:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R
 tail -n 1 $S/bench_n1.json > profiles/${T}_bench_n1.json

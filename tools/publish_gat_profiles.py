@@ -19,7 +19,7 @@ acc = collections.defaultdict(list)
 for sub in ("pmc1", "pmc2"):
     for r in csv.DictReader(open(glob.glob(f"{d}/{sub}/*/*counter_collection.csv")[0])):
         name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
-        if "gemm" in name or "aggregate" in name:
+        if "gemm" in name or "aggregate" in name or "banded" in name:
             acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(f"{P}/{T}_gat_n4541_pmc.csv", "w") as f:
     f.write("kernel,counter,dispatches,avg,min,max\n")

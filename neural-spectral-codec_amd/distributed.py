@@ -408,15 +408,14 @@ class ShardedDescriptorPath:
             return self.gnn(self._graph)
         slot = self._k % self._PIPE_BUFFERS
         folded = None
+        live = inner._live_tensors() if hasattr(inner, "_live_tensors") else list(inner.parameters()) + list(inner.buffers())
         if hasattr(inner, "_model_struct"):
             # the capture bakes in the folded attention vectors the model caches: make sure they exist for the current
             # weights, and key on their generation -- an optimizer that writes through a multi-tensor kernel does not bump
             # the parameters' version counters, GNNTrainer drops the cache after every step instead (a new generation)
-            inner._model_struct()
+            inner._model_struct(live)
             folded = inner._struct_cache[2]
-        key = (x.data_ptr(), tuple(x.shape),
-               tuple((t.data_ptr(), t._version) for t in (inner._live_tensors() if hasattr(inner, "_live_tensors")
-                                                          else list(inner.parameters()) + list(inner.buffers()))),
+        key = (x.data_ptr(), tuple(x.shape), tuple((t.data_ptr(), t._version) for t in live),
                getattr(inner, "coresident", False), getattr(inner, "_fold_generation", 0))
         ent = self._gnn_graphs.get(slot)
         if ent is not None and ent[0] == key:

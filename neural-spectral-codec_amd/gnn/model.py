@@ -217,6 +217,7 @@ class SpectralGNN(nn.Module):
         state["_train_struct_cache"] = None
         state["_seed_dev"] = None
         state["_fold_generation"] = 0
+        state.pop("_live_slots", None)
         state["_direct_grads"] = False
         return state
 
@@ -244,24 +245,31 @@ class SpectralGNN(nn.Module):
         return t.data_ptr()
 
     def _live_tensors(self):
-        """Every tensor NscGatModel points into, by direct attribute access (nn.Module.parameters() / buffers() walk the
-        module tree recursively: 40 % of the host time of a pipelined step went there, round 3)."""
-        ts = [self.input_proj.weight, self.input_proj.bias]
-        for bn in [self.input_norm] + list(self.batch_norms):
-            ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        ts += [self.output_proj.weight, self.output_proj.bias]
-        if self.residual_proj is not None:
-            ts += [self.residual_proj.weight, self.residual_proj.bias]
-        for conv in self.convs:
-            ts += [conv.lin_src.weight, conv.att_src, conv.att_dst, conv.bias]
-            if conv.lin_edge is not None:
-                ts += [conv.lin_edge.weight, conv.att_edge]
-        return ts
+        """Every tensor NscGatModel points into.  Looked up through the modules' own ``_parameters`` / ``_buffers`` dicts (the
+        (dict, name) pairs are collected once: the module tree is fixed after __init__): always the current tensor, without
+        nn.Module.__getattr__ -- 113 attribute walks per call were a third of the host time of a pipelined step (round 4;
+        nn.Module.parameters() / buffers() before that: 40 %, round 3)."""
+        slots = self.__dict__.get("_live_slots")
+        if slots is None:
+            slots = [(self.input_proj._parameters, "weight"), (self.input_proj._parameters, "bias")]
+            for bn in [self.input_norm] + list(self.batch_norms):
+                slots += [(bn._parameters, "weight"), (bn._parameters, "bias"), (bn._buffers, "running_mean"),
+                          (bn._buffers, "running_var")]
+            slots += [(self.output_proj._parameters, "weight"), (self.output_proj._parameters, "bias")]
+            if self.residual_proj is not None:
+                slots += [(self.residual_proj._parameters, "weight"), (self.residual_proj._parameters, "bias")]
+            for conv in self.convs:
+                slots += [(conv.lin_src._parameters, "weight"), (conv._parameters, "att_src"), (conv._parameters, "att_dst"),
+                          (conv._parameters, "bias")]
+                if conv.lin_edge is not None:
+                    slots += [(conv.lin_edge._parameters, "weight"), (conv._parameters, "att_edge")]
+            self.__dict__["_live_slots"] = slots
+        return [d[n] for d, n in slots]
 
-    def _model_struct(self) -> _lib.GatModel:
+    def _model_struct(self, live=None) -> _lib.GatModel:
         """NscGatModel over the live parameter storage.  Rebuilt (and the attention vectors re-folded
-        by nsc_gat_fold_weights) only when a parameter was modified or moved."""
-        key = tuple((t.data_ptr(), t._version) for t in self._live_tensors())
+        by nsc_gat_fold_weights) only when a parameter was modified or moved.  ``live``: the caller's _live_tensors()."""
+        key = tuple((t.data_ptr(), t._version) for t in (live if live is not None else self._live_tensors()))
         if self._struct_cache is not None and self._struct_cache[0] == key:
             return self._struct_cache[1]
         m = self._build_struct()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""One-off soak (not part of the test suite): random irregular graphs through SpectralGNN.forward (both kernel
-sets) and forward_with_attention against the CPU restatement.  usage: fuzz_gat.py [n_graphs]"""
+"""One-off soak (not part of the test suite): random graphs through SpectralGNN.forward -- every kernel set, the one-launch
+banded layers of round 4 included (two graph kinds in seven are random BANDED multigraphs: sources within 2 rows, shuffled and
+duplicated edges, at most 8 entries per target) -- against each other bit for bit and against the CPU restatement.
+usage: fuzz_gat.py [n_graphs]"""
 import os
 import sys
 import time
@@ -20,14 +22,38 @@ rng = np.random.default_rng(2024)
 worst = 0.0
 t0 = time.time()
 for gi in range(n_graphs):
-    edge_dim = [2, None, 3][gi % 3]
+    edge_dim = [2, None, 3][gi % 3] if gi % 7 < 5 else [2, None][gi % 2]
     torch.manual_seed(gi)
     m = create_spectral_gnn(edge_dim=edge_dim)
     go.randomize_bn_stats(m, gi)
     m = m.to("cuda").eval()
     n = int(rng.integers(1, 1500)) if gi % 10 else int(rng.integers(2400, 6000))   # every 10th: past the switch to 64 x 64 tiles
-    kind = gi % 5
-    if kind == 0:                                   # random sparse, duplicates and self loops allowed
+    kind = gi % 7
+    want_band = None
+    if kind >= 5:                                   # banded multigraph (the temporal chain's shape, perturbed): takes gat_layer_banded_kernel
+        tn = [5, 3][kind - 5]
+        half = tn // 2
+        src, dst = [], []
+        for off in range(-half, half + 1):
+            if off == 0:
+                continue
+            i = np.arange(max(0, -off), min(n, n - off))
+            src.append(i + off); dst.append(i)
+        base = np.stack([np.concatenate(src), np.concatenate(dst)]) if src and n > 1 else np.zeros((2, 0), np.int64)
+        if base.shape[1]:
+            dup = base[:, rng.choice(base.shape[1], base.shape[1] // 5, replace=False)]      # a fifth of the edges twice
+            loops = np.stack([np.arange(0, n, 5), np.arange(0, n, 5)])                           # explicit self loops: removed, re-added
+            ei = np.concatenate([base, dup, loops], 1)
+            ei = ei[:, rng.permutation(ei.shape[1])]
+            keep, cnt = [], np.zeros(n, int)
+            for a_, b_ in ei.T:                          # at most 7 real edges per target (+ the self loop = 8 slots)
+                if a_ == b_ or cnt[b_] < 7:
+                    keep.append((a_, b_)); cnt[b_] += a_ != b_
+            ei = np.array(keep).T
+        else:
+            ei = base
+        want_band = 2
+    elif kind == 0:                                   # random sparse, duplicates and self loops allowed
         e = int(rng.integers(0, 6 * n + 1))
         ei = rng.integers(0, n, (2, e))
     elif kind == 1:                                 # hubs: a few nodes receive hundreds of edges (deg > 64 path)
@@ -57,12 +83,17 @@ for gi in range(n_graphs):
         c = m(g)
         m.gnn.coresident = "lds_tiled"
         d = m(g)
+        m.gnn.coresident = "generic"
+        e_ = m(g)
         m.gnn.coresident = False
-    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d), f"graph {gi}: kernel sets differ"
+        if want_band is not None:
+            use_edge = g.edge_attr is not None and m.gnn.edge_dim is not None
+            assert m.gnn._csr(g, use_edge).band == want_band, f"graph {gi}: expected the banded path"
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and torch.equal(a, e_), f"graph {gi}: kernel sets differ"
     ref = go.forward_reference(m, g)
     err = ((a.cpu() - ref).abs().max() / ref.abs().max()).item()
     worst = max(worst, err)
     assert err < 1e-4, f"graph {gi} (kind {kind}, n {n}, E {ei.shape[1]}): rel err {err}"
     if gi % 20 == 19:
         print(f"{gi + 1} graphs, worst rel err {worst:.2e} ({time.time() - t0:.0f} s)", flush=True)
-print(f"TOTAL {n_graphs} graphs: all four kernel sets bit-identical, worst relative error vs restatement {worst:.2e}")
+print(f"TOTAL {n_graphs} graphs: all five kernel sets (the one-launch banded layers on 2 kinds in 7) bit-identical, worst relative error vs restatement {worst:.2e}")

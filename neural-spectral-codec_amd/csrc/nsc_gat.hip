@@ -267,10 +267,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
     // A wave whose columns all lie beyond N only helps with the staging (the fifth column block of the lin GEMMs
     // carries just the two attention columns): it skips the operand reads and the MFMAs.
     const bool active = n0 + wc * 16 * ACN < N;
-#ifdef NSC_DEV_TUNING
-    f32x4 dev_c = {1.0f + (float)lane, 0.5f, 0.25f, 2.0f};
-    asm volatile("" : "+v"(dev_c));
-#endif
 
     // Register ring of PD chunks: every global load of the next PD chunks is in flight while the current
     // chunk's MFMAs run, so one L2 round trip is exposed per kernel instead of one per chunk (these GEMMs
@@ -312,18 +308,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 #pragma unroll
                 for (int d = 0; d < BK / 16; ++d) {
                     if (16 * d < kleft && active) {
-#ifdef NSC_DEV_TUNING
-                        if (ep.dev & 4) {                  // no LDS operand reads: MFMAs on loop-invariant registers
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                                for (int h = 0; h < ACC; ++h)
-#pragma unroll
-                                    for (int g = 0; g < ACN; ++g)
-                                        acc[h][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(dev_c[t], dev_c[3 - t], acc[h][g], 0, 0, 0);
-                            continue;
-                        }
-#endif
                         f32x4 bv[ACN], av[ACC];
 #pragma unroll
                         for (int g = 0; g < ACN; ++g)
@@ -331,15 +315,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
 #pragma unroll
                         for (int h = 0; h < ACC; ++h)
                             av[h] = *reinterpret_cast<const f32x4 *>(&as[(wr * 16 * ACC + 16 * h + r) * LD + 16 * d + 4 * q]);
-#ifdef NSC_DEV_TUNING
-                        if (ep.dev & 1) {                  // no MFMAs: keep the operand reads alive
-#pragma unroll
-                            for (int h = 0; h < ACC; ++h)
-#pragma unroll
-                                for (int g = 0; g < ACN; ++g) acc[h][g] += av[h] * bv[g];
-                            continue;
-                        }
-#endif
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -355,9 +330,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float *__restrict__ 
                     for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&As[cur ^ 1][sa[i]]) = ra[ns][i];
 #pragma unroll
                     for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(&Bs[cur ^ 1][sb[i]]) = rb[ns][i];
-#ifdef NSC_DEV_TUNING
-                    if (!(ep.dev & 2))
-#endif
                     if (ch + 1 + PD < nchunks) load_chunk(ch + 1 + PD, ra[ns], rb[ns]);
                 }
                 __syncthreads();
@@ -933,13 +905,6 @@ int check_model(const NscGatModel *m)
     return NSC_OK;
 }
 
-#ifdef NSC_DEV_TUNING
-int gat_tune_env(const char *name, int def)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : def;
-}
-#endif
 
 template <int EPI>
 void launch_gemm(hipStream_t st, int cores, const float *A, int lda, const float *B, int ldb, const float *Bx,
@@ -980,22 +945,9 @@ void launch_gemm(hipStream_t st, int cores, const float *A, int lda, const float
             if (s != 1) four = false;
         }
     }
-    unsigned pad = 0;
-#ifdef NSC_DEV_TUNING
-    const int force = gat_tune_env("NSC_TUNE_GEMM_ACC", 0);
-    if (force == 1) two = four = false;
-    if (force == 2) { two = !coresident; four = false; }
-    if (force == 4) four = !coresident;
-    pad = (unsigned)gat_tune_env("NSC_TUNE_GEMM_LDSPAD", 0);
-#endif
     const int bm = four ? 64 : two ? 32 : 16;
     const dim3 grid((N + 63) / 64, (M + bm - 1) / bm);
-    const unsigned lds = (unsigned)(2 * (bm + 64) * 68 * sizeof(float)) + pad;
-#ifdef NSC_DEV_TUNING
-    GemmEpi epd = ep;
-    epd.dev = gat_tune_env("NSC_TUNE_GEMM_ABL", 0);
-#define ep epd
-#endif
+    const unsigned lds = (unsigned)(2 * (bm + 64) * 68 * sizeof(float));
     if (coresident) {
         // Round 3: 32-row tiles (two accumulators share every B operand) with a 2-deep register ring -- 54 VGPRs, so two of
         // its waves still share a SIMD with five encoder workgroups.  Beside an HBM-saturating kernel a co-runner pays for
@@ -1020,9 +972,6 @@ void launch_gemm(hipStream_t st, int cores, const float *A, int lda, const float
             hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), lds, st, A, lda, B, ldb, Bx, M, N, n_main,
                                K, C, ldc, ep);
     }
-#ifdef NSC_DEV_TUNING
-#undef ep
-#endif
 }
 
 }  // namespace

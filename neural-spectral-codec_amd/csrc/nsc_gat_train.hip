@@ -474,11 +474,25 @@ __device__ __forceinline__ float wave_maxf(float v)
 }
 
 // a_src[i] = <g_i, att_src>, a_dst[i] = <g_i, att_dst>; one wave per node
+// (round 4: the last workgroup of the grid computes v = W_edge^T att_edge instead -- edge_vec_kernel's body, which was a launch
+// of its own per layer and batch)
 __global__ __launch_bounds__(256) void att_dots_kernel(const float *__restrict__ G, const float *__restrict__ att_s,
                                                        const float *__restrict__ att_d, int N, int H,
-                                                       float *__restrict__ a_src, float *__restrict__ a_dst)
+                                                       float *__restrict__ a_src, float *__restrict__ a_dst,
+                                                       const float *__restrict__ w_edge, const float *__restrict__ att_edge,
+                                                       int edge_dim, float *__restrict__ v)
 {
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w_edge && blockIdx.x == gridDim.x - 1) {
+        // one wavefront per component d: lane-strided partial dot products, then the xor-shuffle tree
+        for (int d = threadIdx.x >> 6; d < edge_dim; d += 4) {
+            float s = 0.0f;
+            for (int c = lane; c < H; c += 64) s = __builtin_fmaf(w_edge[(long long)c * edge_dim + d], att_edge[c], s);
+            s = wave_sumf(s);
+            if (lane == 0) v[d] = s;
+        }
+        return;
+    }
     if (i >= N) return;
     float s = 0.f, d = 0.f;
     for (int c = lane; c < H; c += 64) {
@@ -845,46 +859,34 @@ __global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restric
     }
 }
 
-__global__ __launch_bounds__(64) void edge_term_bwd_final_kernel(const double *__restrict__ part, int nparts,
-                                                                 int edge_dim, float *__restrict__ dv)
+// (round 4: one launch instead of edge_term_bwd_final_kernel + edge_vec_bwd_kernel)  dv[d] = sum of the workgroups' partials in a
+// fixed shuffle tree (deterministic), then the backward of v = W_edge^T att_edge: dW_edge[c,d] = dv[d] att_edge[c],
+// datt_edge[c] = sum_d dv[d] W_edge[c,d]
+__global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const double *__restrict__ part, int nparts,
+                                                           const float *__restrict__ w_edge, const float *__restrict__ att_edge,
+                                                           int H, int edge_dim, float *__restrict__ dw_edge,
+                                                           float *__restrict__ datt_edge, int accumulate)
 {
-    // lane g holds partial g (nparts <= 64); fixed shuffle tree -> deterministic
-    const int lane = threadIdx.x;
-    for (int d = 0; d < edge_dim; ++d) {
-        double s = lane < nparts ? part[lane * NSC_GAT_MAX_EDGE_DIM + d] : 0.0;
+    __shared__ float dv[NSC_GAT_MAX_EDGE_DIM];
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;                        // lane g holds partial g (nparts <= 64)
+        for (int d = 0; d < edge_dim; ++d) {
+            double s = lane < nparts ? part[lane * NSC_GAT_MAX_EDGE_DIM + d] : 0.0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) dv[d] = (float)s;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) dv[d] = (float)s;
+        }
     }
-}
-
-// v = W_edge^T att_edge (forward) and its backward: dW_edge[c,d] = dv[d] att_edge[c]; datt_edge[c] = sum_d dv[d] W_edge[c,d]
-__global__ __launch_bounds__(256) void edge_vec_kernel(const float *__restrict__ w_edge, const float *__restrict__ att_edge,
-                                                       int H, int edge_dim, float *__restrict__ v)
-{
-    // one wavefront per component d: lane-strided partial dot products, then the xor-shuffle tree
-    const int lane = threadIdx.x & 63;
-    for (int d = threadIdx.x >> 6; d < edge_dim; d += 4) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
         float s = 0.0f;
-        for (int c = lane; c < H; c += 64) s = __builtin_fmaf(w_edge[(long long)c * edge_dim + d], att_edge[c], s);
-        s = wave_sumf(s);
-        if (lane == 0) v[d] = s;
+        for (int d = 0; d < edge_dim; ++d) {
+            const float gw = dv[d] * att_edge[c];
+            dw_edge[(long long)c * edge_dim + d] = accumulate ? dw_edge[(long long)c * edge_dim + d] + gw : gw;
+            s = __builtin_fmaf(dv[d], w_edge[(long long)c * edge_dim + d], s);
+        }
+        datt_edge[c] = accumulate ? datt_edge[c] + s : s;
     }
-}
-__global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const float *__restrict__ w_edge, const float *__restrict__ att_edge,
-                                                           const float *__restrict__ dv, int H, int edge_dim,
-                                                           float *__restrict__ dw_edge, float *__restrict__ datt_edge,
-                                                           int accumulate)
-{
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= H) return;
-    float s = 0.0f;
-    for (int d = 0; d < edge_dim; ++d) {
-        const float gw = dv[d] * att_edge[c];
-        dw_edge[(long long)c * edge_dim + d] = accumulate ? dw_edge[(long long)c * edge_dim + d] + gw : gw;
-        s = __builtin_fmaf(dv[d], w_edge[(long long)c * edge_dim + d], s);
-    }
-    datt_edge[c] = accumulate ? datt_edge[c] + s : s;
 }
 
 // transposed CSR (entries grouped by source) from the forward CSR
@@ -1217,9 +1219,8 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
         float *alpha = F(w.alpha + w.nz * l), *y = F(w.y + w.nh * l);
         float *mean = F(w.mean + w.hh * l), *invstd = F(w.invstd + w.hh * l), *vv = F(w.vvec + 256 * l);
         gemm<false, false>(st, hin, H, Ly.lin_w, H, N, H, H, G, H, nullptr, 0, 1, nullptr);
-        hipLaunchKernelGGL(att_dots_kernel, dim3((N + 3) / 4), dim3(256), 0, st, G, Ly.att_src, Ly.att_dst, N, H, as, ad);
-        if (use_edge)
-            hipLaunchKernelGGL(edge_vec_kernel, dim3(1), dim3(256), 0, st, Ly.lin_edge_w, Ly.att_edge, H, m->edge_dim, vv);
+        hipLaunchKernelGGL(att_dots_kernel, dim3((N + 3) / 4 + (use_edge ? 1 : 0)), dim3(256), 0, st, G, Ly.att_src, Ly.att_dst, N, H, as, ad,
+                           use_edge ? Ly.lin_edge_w : nullptr, Ly.att_edge, m->edge_dim, vv);
         TrainAgg a;
         a.row_ptr = g->row_ptr; a.src = g->src; a.eid = g->eid;
         a.loop_attr = use_edge ? g->loop_attr : nullptr;
@@ -1360,9 +1361,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
             if (use_edge) {
                 hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,
                                    g->loop_attr, edge_attr, F(w.draw), N, m->edge_dim, colpart);
-                hipLaunchKernelGGL(edge_term_bwd_final_kernel, dim3(1), dim3(64), 0, st, colpart, EDGE_BWD_WGS, m->edge_dim,
-                                   F(w.dvvec));
-                hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(blocks(H)), dim3(256), 0, st, Ly.lin_edge_w, Ly.att_edge, F(w.dvvec),
+                hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(1), dim3(256), 0, st, colpart, EDGE_BWD_WGS, Ly.lin_edge_w, Ly.att_edge,
                                    H, m->edge_dim, Gl.lin_edge_w, Gl.att_edge, acc);
             } else if (!acc) {                      // no edge term in this forward: zero gradient (nothing to add when accumulating)
                 if (hipMemsetAsync(Gl.lin_edge_w, 0, (size_t)H * m->edge_dim * 4, st) != hipSuccess) return NSC_ELAUNCH;

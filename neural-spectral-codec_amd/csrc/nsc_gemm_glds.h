@@ -31,9 +31,6 @@ struct GemmEpi {
     const float *resid;                             // (M, ldr) added last, nullable
     int ldr;
     float *aux0, *aux1;                             // columns n_main, n_main+1 (M each), nullable
-#ifdef NSC_DEV_TUNING
-    int dev;                                        // ablation bits (development builds, NSC_TUNE_GEMM_ABL): 1 no MFMAs, 2 no refills, 4 no LDS operand reads
-#endif
 };
 
 // EPI: 0 = plain store + aux columns (lin), 1 = bias + BatchNorm + ReLU (input_proj),

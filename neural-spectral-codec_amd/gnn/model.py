@@ -103,72 +103,86 @@ class GraphCSR:
         return g
 
 
+def _train_forward_raw(gnn, x, csr, dropout_p, seed):
+    """nsc_gat_forward_train: returns (out, state); state holds the workspace with the saved activations for
+    _train_backward_raw.  Used by the autograd Function below and, without autograd, by GNNTrainer's direct step."""
+    L = _lib.lib()
+    dev = x.device
+    m = gnn._train_struct()
+    csr.ensure_transpose()
+    g = csr.struct()
+    cfg = _lib.GatTrainCfg()
+    cfg.dropout_p, cfg.bn_momentum = float(dropout_p), float(gnn.input_norm.momentum or 0.1)
+    cfg.seed, cfg.update_running_stats = int(seed), 1
+    sd = getattr(gnn, "_seed_dev", None)          # a device word the kernels read the seed from (captured steps)
+    cfg.seed_dev = sd.data_ptr() if sd is not None else None
+    n = int(x.shape[0])
+    out = torch.empty((n, gnn.output_dim), dtype=torch.float32, device=dev)
+    nbytes = L.nsc_gat_train_workspace_bytes(C.byref(m), C.byref(g))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # holds the saved activations
+    with torch.cuda.device(dev):
+        st = L.nsc_gat_forward_train(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
+                                     C.byref(cfg), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+    _lib.check(st, "nsc_gat_forward_train")
+    for bn in [gnn.input_norm] + list(gnn.batch_norms):
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    return out, (csr, cfg, ws, nbytes, x, sd)
+
+
+def _train_backward_raw(gnn, state, grad_out, grads, accumulate, need_x):
+    """nsc_gat_backward into ``grads`` (tensors in _train_params() order; accumulate: added to what they hold).  Returns the
+    gradient w.r.t. x or None."""
+    csr, cfg, ws, nbytes, x, _sd = state
+    L = _lib.lib()
+    dev = x.device
+    m = gnn._train_struct()
+    g = csr.struct()
+    cfg.accumulate_grads = 1 if accumulate else 0
+    gs = _lib.GatGrads()
+    it = iter(grads)
+    gs.in_w, gs.in_b = next(it).data_ptr(), next(it).data_ptr()
+    gs.in_bn_w, gs.in_bn_b = next(it).data_ptr(), next(it).data_ptr()
+    gs.out_w, gs.out_b = next(it).data_ptr(), next(it).data_ptr()
+    if gnn.residual_proj is not None:
+        gs.res_w, gs.res_b = next(it).data_ptr(), next(it).data_ptr()
+    for l, conv in enumerate(gnn.convs):
+        gl = gs.layers[l]
+        gl.lin_w, gl.att_src, gl.att_dst = next(it).data_ptr(), next(it).data_ptr(), next(it).data_ptr()
+        if conv.lin_edge is not None:
+            gl.lin_edge_w, gl.att_edge = next(it).data_ptr(), next(it).data_ptr()
+        gl.bias, gl.bn_w, gl.bn_b = next(it).data_ptr(), next(it).data_ptr(), next(it).data_ptr()
+    gx = torch.empty_like(x) if need_x else None
+    gs.x = gx.data_ptr() if gx is not None else None
+    with torch.cuda.device(dev):
+        st = L.nsc_gat_backward(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
+                                C.byref(cfg), _lib.ptr(grad_out), C.byref(gs), _lib.ptr(ws), nbytes,
+                                _lib.stream_ptr(dev))
+    _lib.check(st, "nsc_gat_backward")
+    return gx
+
+
 class _GatTrainFunction(torch.autograd.Function):
     """model.train(); model(data) with autograd: nsc_gat_forward_train / nsc_gat_backward."""
 
     @staticmethod
     def forward(ctx, gnn, x, csr, dropout_p, seed, *params):
-        L = _lib.lib()
-        dev = x.device
-        m = gnn._train_struct()
-        csr.ensure_transpose()
-        g = csr.struct()
-        cfg = _lib.GatTrainCfg()
-        cfg.dropout_p, cfg.bn_momentum = float(dropout_p), float(gnn.input_norm.momentum or 0.1)
-        cfg.seed, cfg.update_running_stats = int(seed), 1
-        sd = getattr(gnn, "_seed_dev", None)          # a device word the kernels read the seed from (captured steps)
-        cfg.seed_dev = sd.data_ptr() if sd is not None else None
-        ctx.seed_dev = sd
-        n = int(x.shape[0])
-        out = torch.empty((n, gnn.output_dim), dtype=torch.float32, device=dev)
-        nbytes = L.nsc_gat_train_workspace_bytes(C.byref(m), C.byref(g))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # holds the saved activations
-        with torch.cuda.device(dev):
-            st = L.nsc_gat_forward_train(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
-                                         C.byref(cfg), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
-        _lib.check(st, "nsc_gat_forward_train")
-        for bn in [gnn.input_norm] + list(gnn.batch_norms):
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
-        ctx.gnn, ctx.csr, ctx.cfg, ctx.ws, ctx.nbytes, ctx.x = gnn, csr, cfg, ws, nbytes, x
+        out, state = _train_forward_raw(gnn, x, csr, dropout_p, seed)
+        ctx.gnn, ctx.state = gnn, state
         ctx.need_x = x.requires_grad
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        gnn, csr, x = ctx.gnn, ctx.csr, ctx.x
-        L = _lib.lib()
-        dev = x.device
-        m = gnn._train_struct()
-        g = csr.struct()
+        gnn = ctx.gnn
         params = gnn._train_params()
         # GNNTrainer's steps: the kernels ADD into the existing .grad tensors (NscGatTrainCfg.accumulate_grads) and autograd
         # gets no parameter gradients back -- no AccumulateGrad axpy per parameter (30 small kernels per batch)
         direct = bool(getattr(gnn, "_direct_grads", False)) and all(p.grad is not None and p.grad.is_contiguous() for p in params)
         grads = [p.grad for p in params] if direct else [torch.empty_like(p) for p in params]
-        ctx.cfg.accumulate_grads = 1 if direct else 0
-        gs = _lib.GatGrads()
-        it = iter(grads)
-        gs.in_w, gs.in_b = next(it).data_ptr(), next(it).data_ptr()
-        gs.in_bn_w, gs.in_bn_b = next(it).data_ptr(), next(it).data_ptr()
-        gs.out_w, gs.out_b = next(it).data_ptr(), next(it).data_ptr()
-        if gnn.residual_proj is not None:
-            gs.res_w, gs.res_b = next(it).data_ptr(), next(it).data_ptr()
-        for l, conv in enumerate(gnn.convs):
-            gl = gs.layers[l]
-            gl.lin_w, gl.att_src, gl.att_dst = next(it).data_ptr(), next(it).data_ptr(), next(it).data_ptr()
-            if conv.lin_edge is not None:
-                gl.lin_edge_w, gl.att_edge = next(it).data_ptr(), next(it).data_ptr()
-            gl.bias, gl.bn_w, gl.bn_b = next(it).data_ptr(), next(it).data_ptr(), next(it).data_ptr()
-        gx = torch.empty_like(x) if ctx.need_x else None
-        gs.x = gx.data_ptr() if gx is not None else None
         go = grad_out.contiguous().float()
-        with torch.cuda.device(dev):
-            st = L.nsc_gat_backward(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
-                                    C.byref(ctx.cfg), _lib.ptr(go), C.byref(gs), _lib.ptr(ctx.ws), ctx.nbytes,
-                                    _lib.stream_ptr(dev))
-        _lib.check(st, "nsc_gat_backward")
-        ctx.ws = None
+        gx = _train_backward_raw(gnn, ctx.state, go, grads, direct, ctx.need_x)
+        ctx.state = None
         if direct:
             return (None, gx, None, None, None) + (None,) * len(grads)
         return (None, gx, None, None, None, *grads)
@@ -346,6 +360,37 @@ class SpectralGNN(nn.Module):
         # device word instead (self._seed_dev), rewritten before every replay
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and getattr(self, "_seed_dev", None) is None) else 0
         return _GatTrainFunction.apply(self, x, csr, float(self.dropout), seed, *self._train_params())
+
+    def train_step_direct(self, data, anchor_idx, positive_idx, negative_idx, margin: float, scale: float):
+        """forward (train mode) + TripletLoss + backward WITHOUT autograd (GNNTrainer's steps, round 4): nsc_gat_forward_train,
+        nsc_triplet_loss (which returns d loss / d emb) and nsc_gat_backward adding into the parameters' existing .grad
+        tensors -- what ``loss = criterion(model(graph)[a], ...); loss.backward()`` (trainer.py:205-213) computes, minus the
+        autograd plumbing around the three ABI calls (a (N, 800) multiply by the upstream scalar, two dtype / layout copies and
+        the engine's bookkeeping per batch).  Indices: int64 device tensors.  Returns the loss (0-d tensor)."""
+        x = data.x
+        _lib.require_cuda(x, "data.x")
+        x = x.detach().to(torch.float32).contiguous()
+        edge_attr = getattr(data, 'edge_attr', None)
+        csr = self._csr(data, edge_attr is not None and self.edge_dim is not None)
+        params = self._train_params()
+        if any(p.grad is None or not p.grad.is_contiguous() for p in params):
+            raise _lib.NscError("train_step_direct adds into existing contiguous .grad tensors")
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (self.dropout > 0 and getattr(self, "_seed_dev", None) is None) else 0
+        out, state = _train_forward_raw(self, x, csr, float(self.dropout), seed)
+        L = _lib.lib()
+        dev = x.device
+        n, d, t = int(out.shape[0]), int(out.shape[1]), int(anchor_idx.numel())
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(out)
+        nbytes = L.nsc_triplet_workspace_bytes(t)
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            st = L.nsc_triplet_loss(_lib.ptr(out), _lib.ptr(anchor_idx), _lib.ptr(positive_idx), _lib.ptr(negative_idx), t, n, d,
+                                    float(margin), float(scale), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws), nbytes,
+                                    _lib.stream_ptr(dev))
+        _lib.check(st, "nsc_triplet_loss")
+        _train_backward_raw(self, state, grad, [p.grad for p in params], True, False)
+        return loss[0]
 
     def _run(self, data, use_edge_attr: bool, want_alpha: bool):
         x = data.x

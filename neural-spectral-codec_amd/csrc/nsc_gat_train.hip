@@ -248,6 +248,32 @@ __device__ __forceinline__ void colreduce_finish(const double *__restrict__ part
     }
 }
 
+// The sum of the R partial rows for the 64 columns of a column block, by the workgroup that CONSUMES it (round 4: the forward's
+// BatchNorm apply and the backward's apply pass finish the reduction of the pass before them themselves -- 64 x 64 x 16 bytes of
+// L2 hits per workgroup instead of a 5 us launch per reduction).  Same order of additions as colreduce_finish: wave ry sums rows
+// ry, ry + 4, ..., then (w0 + w1) + (w2 + w3).  All 256 threads call it; the sums of column cx are returned to every thread.
+__device__ __forceinline__ void colreduce_local(const double *__restrict__ part, int R, int C, int c, int cx, int ry,
+                                                double *sa, double *sb, double &a_out, double &b_out)
+{
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        int r = ry;
+        for (; r + 28 < R; r += 32) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(&part[((long long)(r + 4 * u) * C + c) * 2]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
+        }
+        for (; r < R; r += 4) { a += part[((long long)r * C + c) * 2]; b += part[((long long)r * C + c) * 2 + 1]; }
+    }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    a_out = (sa[cx] + sa[64 + cx]) + (sa[128 + cx] + sa[192 + cx]);
+    b_out = (sb[cx] + sb[64 + cx]) + (sb[128 + cx] + sb[192 + cx]);
+    __syncthreads();
+}
+
 // Pass 1: every workgroup reduces its rows of a 64-column block to float64 partials.
 // (Round 3 measured both passes fused into ONE launch -- the last workgroup of a column block to arrive, by a device-scope
 // ticket, finishing the sum: the release / acquire fences it needs are an L2 write-back + invalidate on an 8-XCD part, and the
@@ -393,17 +419,27 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(const float *__restr
 // sum_n dZ[n][c] (the gradient of the bias in front of this BatchNorm; a final pass adds them up: ColExtra).
 __global__ __launch_bounds__(256) void bn_apply_colsum_kernel(float *__restrict__ dv, const float *__restrict__ z,
                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                              const float *__restrict__ gamma, const float *__restrict__ s1,
-                                                              const float *__restrict__ s2, int N, int C, int rows_per_block,
+                                                              const float *__restrict__ gamma, const double *__restrict__ part_in,
+                                                              int R, float *__restrict__ g_bn_b, float *__restrict__ g_bn_w,
+                                                              int acc, int N, int C, int rows_per_block,
                                                               double *__restrict__ part)
 {
-    __shared__ double sa[256];
+    __shared__ double sa[256], sb[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+    // s1 = sum dV, s2 = sum dV xhat: the finish of bn_bwd_colsum_kernel's partials (their float values, as the separate final
+    // pass stored them); the first row block also stores them as the BatchNorm parameter gradients
+    double d1, d2;
+    colreduce_local(part_in, R, C, c, cx, ry, sa, sb, d1, d2);
+    const float t1 = (float)d1, t2 = (float)d2;
+    if (blockIdx.y == 0 && ry == 0 && c < C) {
+        g_bn_b[c] = acc ? g_bn_b[c] + t1 : t1;
+        g_bn_w[c] = acc ? g_bn_w[c] + t2 : t2;
+    }
     double a = 0.0;
     if (c < C) {
-        const float m = mean[c], s = invstd[c], ga = gamma[c], t1 = s1[c], t2 = s2[c];
+        const float m = mean[c], s = invstd[c], ga = gamma[c];
         const float invn = 1.0f / (float)N;
         auto step = [&](int n, float dvv, float zv) {
             const float xhat = (zv - m) * s;
@@ -432,22 +468,59 @@ __global__ __launch_bounds__(256) void bn_apply_colsum_kernel(float *__restrict_
 // ---------------------------------------------------------------------------------------------
 // BatchNorm(train) apply + ReLU + dropout + residual:  h = drop(relu(gamma*xhat + beta)) + resid
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ z, const float *__restrict__ mean,
-                                                     const float *__restrict__ invstd,
-                                                     const float *__restrict__ gamma,
+// (round 4: column-blocked, and it finishes the batch statistics of the reduction before it itself -- mean = A / N,
+// var = B / N - mean^2, invstd = 1 / sqrt(var + eps) in float64 from the float64 partials, exactly colreduce_finish's mode 1;
+// the first row block stores mean / invstd for the backward and updates the running statistics)
+__global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ z, const double *__restrict__ part_in, int R,
+                                                     float eps, float momentum, float *__restrict__ mean_out,
+                                                     float *__restrict__ invstd_out, float *__restrict__ run_mean,
+                                                     float *__restrict__ run_var, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, int relu, float p,
-                                                     SeedRef seed, unsigned stream,
-                                                     const float *__restrict__ resid, long long total, int C,
-                                                     float *__restrict__ out)
+                                                     SeedRef seed, unsigned stream, const float *__restrict__ resid, int N, int C,
+                                                     int rows_per_block, float *__restrict__ out)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-    if (relu) v = fmaxf(v, 0.0f);
-    v *= keep_scale(p, seed.get(), stream, (unsigned long long)i);
-    if (resid) v += resid[i];
-    out[i] = v;
+    __shared__ double sa[256], sb[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+    double a, b;
+    colreduce_local(part_in, R, C, c, cx, ry, sa, sb, a, b);
+    if (c >= C) return;
+    const double dmean = a / N;
+    double var = b / N - dmean * dmean;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)dmean, s = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.y == 0 && ry == 0) {
+        mean_out[c] = m;
+        invstd_out[c] = s;
+        if (run_mean) {                                   // nn.BatchNorm1d: momentum 0.1, unbiased running_var
+            const double unb = N > 1 ? var * N / (N - 1) : var;
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)dmean;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unb;
+        }
+    }
+    const float ga = gamma[c], be = beta[c];
+    const unsigned long long sd = p > 0.0f ? seed.get() : 0ull;
+    auto step = [&](int n, float zv, float rv) {
+        const long long i = (long long)n * C + c;
+        float v = (zv - m) * s * ga + be;
+        if (relu) v = fmaxf(v, 0.0f);
+        v *= keep_scale(p, sd, stream, (unsigned long long)i);
+        if (resid) v += rv;
+        out[i] = v;
+    };
+    int n = n0 + ry;
+    for (; n + 28 < n1; n += 32) {
+        float z8[8], r8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            z8[u] = z[(long long)(n + 4 * u) * C + c];
+            r8[u] = resid ? resid[(long long)(n + 4 * u) * C + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(n + 4 * u, z8[u], r8[u]);
+    }
+    for (; n < n1; n += 4) step(n, z[(long long)n * C + c], resid ? resid[(long long)n * C + c] : 0.0f);
 }
 
 __global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b,
@@ -1105,6 +1178,12 @@ inline int colred_rows(int N)
     return R < 1 ? 1 : R;
 }
 
+// Forward BatchNorm (batch statistics) + activation in two launches (round 3: three): pass 1 of the statistics, then the apply
+// kernel, which finishes them itself (bn_act_kernel).
+void bn_forward(hipStream_t st, const float *z, int N, int C, double *part, float eps, float momentum, float *mean, float *invstd,
+                float *run_mean, float *run_var, const float *gamma, const float *beta, int relu, float p, SeedRef seed,
+                unsigned stream, const float *resid, float *out);
+
 void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, const float *qm, const float *qs,
                int N, int C, double *part, int mode, float eps, float momentum, float *out_a,
                float *out_b, float *run_mean, float *run_var, int acc_a = 0, int acc_b = 0, float *copy_a = nullptr,
@@ -1117,9 +1196,23 @@ void colreduce(hipStream_t st, const float *P, const float *w, const float *Q, c
     hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f, extra);
 }
 
-// BatchNorm backward of one layer in three launches (round 3: five): dV + its two column sums; their final (which also stores
-// the BatchNorm parameter gradients); dZ in place + the partials of its column sum, returned as the ColExtra the caller hands
-// to its next final pass (or to bias_final).
+void bn_forward(hipStream_t st, const float *z, int N, int C, double *part, float eps, float momentum, float *mean, float *invstd,
+                float *run_mean, float *run_var, const float *gamma, const float *beta, int relu, float p, SeedRef seed,
+                unsigned stream, const float *resid, float *out)
+{
+    const int R = colred_rows(N);
+    const int rows = (N + R - 1) / R;
+    const dim3 grid((C + 63) / 64, R);
+    hipLaunchKernelGGL(colreduce_partial_kernel, grid, dim3(256), 0, st, z, static_cast<const float *>(nullptr), z,
+                       static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), N, C, rows, part,
+                       static_cast<const float *>(nullptr));
+    hipLaunchKernelGGL(bn_act_kernel, grid, dim3(256), 0, st, z, part, R, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta,
+                       relu, p, seed, stream, resid, N, C, rows, out);
+}
+
+// BatchNorm backward of one layer in TWO launches (round 3: five): dV + the partials of its two column sums; then dZ in place (the
+// kernel finishes those sums itself and stores the BatchNorm parameter gradients) + the partials of ITS column sum, returned as
+// the ColExtra the caller hands to its next final pass (or to bias_final).
 ColExtra bn_backward(hipStream_t st, const float *dh, const float *z, const float *mean, const float *invstd, const float *gamma,
                      const float *beta, int relu, float p, SeedRef seed, unsigned stream, int N, int C, float *dv, float *s1,
                      float *s2, float *g_bn_b, float *g_bn_w, int acc, double *part, double *part2, float *g_bias)
@@ -1129,9 +1222,10 @@ ColExtra bn_backward(hipStream_t st, const float *dh, const float *z, const floa
     const dim3 grid((C + 63) / 64, R);
     hipLaunchKernelGGL(bn_bwd_colsum_kernel, grid, dim3(256), 0, st, dh, z, mean, invstd, gamma, beta, relu, p, seed, stream, N, C,
                        rows, dv, part);
-    const ColFinal f = {0, N, 0.f, 0.f, s1, s2, nullptr, nullptr, 0, 0, g_bn_b, g_bn_w, acc};
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, R, C, f, ColExtra{nullptr, 0, 0, nullptr});
-    hipLaunchKernelGGL(bn_apply_colsum_kernel, grid, dim3(256), 0, st, dv, z, mean, invstd, gamma, s1, s2, N, C, rows, part2);
+    // (round 4, second step: no final launch -- the apply pass finishes s1 / s2 itself and stores the BatchNorm parameter gradients)
+    (void)s1; (void)s2;
+    hipLaunchKernelGGL(bn_apply_colsum_kernel, grid, dim3(256), 0, st, dv, z, mean, invstd, gamma, part, R, g_bn_b, g_bn_w, acc, N, C,
+                       rows, part2);
     return ColExtra{part2, R, acc, g_bias};
 }
 
@@ -1201,16 +1295,13 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
-    const long long NH = (long long)N * H;
     const int upd = cfg->update_running_stats;
 
     // input_proj (bias) -> z0 ; BatchNorm(batch stats) ; ReLU                 model.py:116-118
     gemm<false, false>(st, x, m->in_dim, m->in_w, m->in_dim, N, H, m->in_dim, F(w.z0), H, m->in_b, 0, 1, nullptr);
-    colreduce(st, F(w.z0), nullptr, F(w.z0), nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum,
-              F(w.mean0), F(w.invstd0), upd ? const_cast<float *>(m->in_bn_mean) : nullptr,
-              upd ? const_cast<float *>(m->in_bn_var) : nullptr);
-    hipLaunchKernelGGL(bn_act_kernel, dim3(blocks(NH)), dim3(256), 0, st, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w,
-                       m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, static_cast<const float *>(nullptr), NH, H, F(w.h));
+    bn_forward(st, F(w.z0), N, H, colpart, m->bn_eps, cfg->bn_momentum, F(w.mean0), F(w.invstd0),
+               upd ? const_cast<float *>(m->in_bn_mean) : nullptr, upd ? const_cast<float *>(m->in_bn_var) : nullptr, m->in_bn_w,
+               m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u, nullptr, F(w.h));
 
     for (int l = 0; l < L; ++l) {
         const NscGatLayer &Ly = m->layers[l];
@@ -1235,12 +1326,11 @@ int nsc_gat_forward_train(const NscGatModel *m, const NscGraph *g, const float *
         case 3: hipLaunchKernelGGL(agg_train_kernel<3>, dim3((N + 3) / 4), dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL(agg_train_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, st, a); break;
         }
-        colreduce(st, y, nullptr, y, nullptr, nullptr, N, H, colpart, 1, m->bn_eps, cfg->bn_momentum, mean, invstd,
-                  upd ? const_cast<float *>(Ly.bn_mean) : nullptr, upd ? const_cast<float *>(Ly.bn_var) : nullptr);
         const int act = (l < L - 1);                                           // model.py:135-137
         const float *resid = (m->residual && l > 0 && l < L - 1) ? hin : nullptr;   // model.py:140-141
-        hipLaunchKernelGGL(bn_act_kernel, dim3(blocks(NH)), dim3(256), 0, st, y, mean, invstd, Ly.bn_w, Ly.bn_b, act,
-                           act ? cfg->dropout_p : 0.0f, SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, resid, NH, H, hout);
+        bn_forward(st, y, N, H, colpart, m->bn_eps, cfg->bn_momentum, mean, invstd, upd ? const_cast<float *>(Ly.bn_mean) : nullptr,
+                   upd ? const_cast<float *>(Ly.bn_var) : nullptr, Ly.bn_w, Ly.bn_b, act, act ? cfg->dropout_p : 0.0f,
+                   SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l, resid, hout);
     }
     // output_proj + input residual                                             model.py:144-151
     bool fused_res = false;

@@ -190,6 +190,152 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight gradients  dW[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands k-major (dW = dY^T X: the rows of dY and X are the
+// k index), round 4.  The k-major operands need no transpose when the MFMA operand is read element by element: the tiles go
+// to LDS as they lie in memory, [k][64 m] and [k][64 n], by LDS-DMA (global_load_lds_dwordx4: 16 bytes = four consecutive m of
+// one k; no register ring, no scalar LDS stores -- gemm_gen_kernel<true,true> staged every float4 through four ds_write_b32 and
+// kept one LDS buffer between two barriers per chunk: 18-26 us per product), and lane (r, q) of a 16x16x4 MFMA reads A[k = 4 s + q]
+// [m = .. + r] as one ds_read_b32.  Bank conflicts are avoided on the SOURCE side like in gemm_glds_kernel: the 16-byte slot of
+// m-quad mq in row k sits at slot mq ^ (4 (k mod 4)), so the four k rows a wave instruction reads land in four different bank
+// groups.  64 x 64 tiles of 2 x 2 waves (a 32 x 32 wave tile = four accumulators share two A and two B reads per k-step),
+// four computing + four staging waves, three stages, one raw barrier per 64-deep chunk with the younger chunk's pieces in flight
+// across it, split over K slabs
+// (blockIdx.z) whose sums slab_reduce_kernel adds in fixed order: deterministic.  k order of every output element: ascending.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_tn_glds_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                           int ldb, int M, int N, int K, int kslab,
+                                                           float *__restrict__ slabs, long long slab)
+{
+    constexpr int NST = 3, STAGE = 2 * 64 * 64;                    // floats per stage: A tile [64 k][64 m] | B tile [64 k][64 n]
+    extern __shared__ __attribute__((aligned(1024))) float tn_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k0 = blockIdx.z * kslab, k1 = min(K, k0 + kslab);
+    const int nchunks = (k1 - k0 + 63) >> 6;
+    if (nchunks <= 0) return;                                       // (cannot happen: the host trims empty slabs)
+
+    if (wave8 >= 4) {
+        // ---- staging waves (wave specialisation as in gemm_glds_kernel: an LDS-DMA instruction costs its wave 60-185 cycles of
+        // issue; with the 8 per chunk in the computing waves' own stream the first form of this kernel took 17.6 us per product):
+        // piece p of a chunk = 4 k rows of one tile (1 KiB, lane-linear); 32 pieces per chunk, wave w takes pieces w, w + 4, ...
+        // (pieces 0-15: A rows 4 p .. 4 p + 3, pieces 16-31: B rows)
+        const int kq = lane >> 4, slot = lane & 15;                 // row within the piece, physical 16-byte slot within the row
+        const int mq = slot ^ (kq << 2);                            // logical quad held by that slot: (4 p + kq) mod 4 = kq
+        int ma = m0 + 4 * mq, nb = n0 + 4 * mq;
+        ma = ma + 3 < M ? ma : M - 4;                               // quads past the matrix re-read valid columns: their products only
+        nb = nb + 3 < N ? nb : N - 4;                               // reach outputs that are never stored
+        const float *srcA = A + ma, *srcB = B + nb;
+        auto issue = [&](int ch, int stage) {
+            float *dst = tn_lds + stage * STAGE + wave * 256;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave + 4 * j;                        // uniform
+                int k = k0 + (ch << 6) + 4 * (p & 15) + kq;
+                k = k < K ? k : K - 1;                              // rows past K re-read the last row: masked out of the products
+                const float *g = (p < 16) ? srcA + (long long)k * lda : srcB + (long long)k * ldb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+            }
+        };
+        issue(0, 0);
+        if (1 < nchunks) issue(1, 1);
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) glds_wait_barrier<8>();           // chunk c landed (this wave's 8 pieces of chunk c + 1 may fly on)
+            else glds_wait_barrier<0>();
+            if (c + 2 < nchunks) issue(c + 2, (c + 2) % NST);       // its stage held chunk c - 1: every computing wave is past that
+        }
+        return;
+    }
+
+    // ---- computing waves: 2 x 2, a 32 x 32 tile each
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][2] = {{zero, zero}, {zero, zero}};
+    const int wm = wave >> 1, wn = wave & 1;
+    // operand addresses inside a stage (floats): row k = 4 s + q -> + (4 s + q) * 64; quad (8 wm + 4 mi + r / 4) ^ (4 q), element r % 4
+    int offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA[i] = q * 64 + 4 * ((8 * wm + 4 * i + (r >> 2)) ^ (q << 2)) + (r & 3);
+        offB[i] = 64 * 64 + q * 64 + 4 * ((8 * wn + 4 * i + (r >> 2)) ^ (q << 2)) + (r & 3);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_barrier" ::: "memory");                    // barrier c: chunk c has landed, chunk c - 1 is read
+        const float *st = tn_lds + (c % NST) * STAGE;
+        const int kleft = k1 - (k0 + (c << 6));                    // valid k rows in this chunk
+        if (kleft >= 64) {
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) {
+                float a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a[i] = st[offA[i] + s4 * 256]; b[i] = st[offB[i] + s4 * 256]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            for (int s4 = 0; 4 * s4 < kleft; ++s4) {                // the slab's last, short chunk: k rows past the end count as zero
+                const bool in = 4 * s4 + q < kleft;
+                float a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a[i] = in ? st[offA[i] + s4 * 256] : 0.0f; b[i] = in ? st[offB[i] + s4 * 256] : 0.0f; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    float *Cz = slabs + (long long)blockIdx.z * slab;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 32 * wn + 16 * j + r;
+            if (col >= N) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {                    // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
+                const int row = m0 + 32 * wm + 16 * i + 4 * q + reg;
+                if (row < M) Cz[(long long)row * N + col] = acc[i][j][reg];
+            }
+        }
+}
+
+// dW = A^T B over K slabs on gemm_tn_glds_kernel; false when the operands do not fit it (the caller takes gemm_gen_kernel)
+bool launch_tn_glds(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C,
+                    int accumulate, float *slabs, int max_slabs)
+{
+    if ((lda & 3) || (ldb & 3) || M < 4 || N < 4 || (M & 3) || (N & 3) || K < 1 || !slabs || (reinterpret_cast<unsigned long long>(A) & 15) ||
+        (reinterpret_cast<unsigned long long>(B) & 15))
+        return false;
+    constexpr unsigned lds = 3 * 2 * 64 * 64 * 4;                  // 96 KB: above 64 KB a kernel is opted in, per device
+    static std::atomic<int> opted[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    int o = opted[dev].load(std::memory_order_acquire);
+    if (o == 0) {
+        o = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) == hipSuccess ? 1 : 2;
+        opted[dev].store(o, std::memory_order_release);
+    }
+    if (o != 1) return false;
+    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    int splits = 256 / tiles;                                       // about one round of workgroups on the 256 CUs
+    splits = splits < 1 ? 1 : (splits > max_slabs ? max_slabs : splits);
+    int kslab = (K + splits - 1) / splits;
+    kslab = (kslab + 63) / 64 * 64;
+    splits = (K + kslab - 1) / kslab;                               // no empty slab
+    const long long MN = (long long)M * N;
+    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(512), lds, st, A, lda, B, ldb, M, N, K,
+                       kslab, slabs, MN);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // column reductions over the N rows of an (N, C) matrix, float64 partials, two passes:
 //   out_a[c] = sum_n P[n][c] * (w ? w[n] : 1)
 //   out_b[c] = sum_n P[n][c] * Q'[n][c],  Q' = Q or (Q - qm[c]) * qs[c]        (Q nullable)
@@ -1157,6 +1303,8 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
         if (accumulate) { ep.resid = C; ep.ldr = ldc; }
         if (launch_glds<2>(st, A, lda, Bn, ldn, nullptr, M, N, N, K, C, ldc, ep)) return;
     }
+    if (AKM && BKM && splits > 1 && !bias && ldc == N && launch_tn_glds(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, SPLITK_SLABS))
+        return;
     dim3 grid((N + 63) / 64, (M + 31) / 32, splits);
     if (splits <= 1) {
         hipLaunchKernelGGL((gemm_gen_kernel<AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, K, K, C, ldc,

@@ -1294,6 +1294,14 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
         const float *Bn = B;
         int ldn = ldb;
         if (BKM) {
+            // round 4: the k-major weight read element-wise from an untransposed LDS tile -- no transposed copy (a 5 us kernel per
+            // product); anything that form cannot take goes through the copy as before
+            GemmEpi e0 = {};
+            e0.bias = bias;
+            if (accumulate) { e0.resid = C; e0.ldr = ldc; }
+            if (launch_glds_bkm(st, A, lda, B, ldb, M, N, K, C, ldc, e0)) return;
+        }
+        if (BKM) {
             hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, st, B, K, N, ldb, slabs);
             Bn = slabs;
             ldn = K;

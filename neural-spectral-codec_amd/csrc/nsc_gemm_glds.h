@@ -66,7 +66,12 @@ template <int N_> __device__ __forceinline__ void glds_wait_barrier()
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N_) : "memory");
 }
 
-template <int ACC, int EPI, int NST = 3, int BC = 1>   // tile (16 ACC) x (64 BC); a computing wave owns ACC x BC accumulators
+// BKM (round 4, the training backward's dX = dY W products, BC = 1 only): B is K-MAJOR, B(n, k) = B[k * ldb + n] -- the weight as it lies
+// in memory when the product contracts over its rows.  Its tile goes to LDS untransposed, [64 k][64 n] (one LDS-DMA quad = four
+// consecutive n of one k; slot of n-quad nq in row k: nq ^ 4 ((k / 4) mod 4), so the four k rows 4 q + t of an operand read land in
+// four bank groups), and lane (r, q) reads its operand element t = B[k = 16 d + 4 q + t][n] as one ds_read_b32: the same k for the
+// same (d, q, t) as the k-contiguous form, so the chain per output element is unchanged -- no transposed copy of the weight.
+template <int ACC, int EPI, int NST = 3, int BC = 1, bool BKM = false>   // tile (16 ACC) x (64 BC); a computing wave owns ACC x BC accumulators
 __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict__ A, int lda,
                                                            const float *__restrict__ B, int ldb,
                                                            const float *__restrict__ Bx, int M, int N,
@@ -77,6 +82,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
     constexpr int STAGE = ROWS * 64;                                // floats per stage
     constexpr int LD = BN + 4;                                      // epilogue staging stride
     static_assert(BM * LD + 3 * BN <= NST * STAGE, "the epilogue tile (+ the folded BatchNorm of its columns) reuses the stages");
+    static_assert(!BKM || BC == 1, "the k-major B tile is laid out for 64 columns");
     extern __shared__ __attribute__((aligned(1024))) float gemm_lds[];   // the ONLY LDS object of the kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,10 +148,17 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
             if (4 * (wave + 4 * j) < BM) {                          // wave-uniform: a piece is all A or all B
                 const int gr = m0 + R;
                 p = A + (long long)(gr < M ? gr : M - 1) * lda;
-            } else {
+            } else if (!BKM) {
                 int gc = n0 + R - BM;
                 gc = gc < N ? gc : N - 1;
                 p = (gc < n_main) ? B + (long long)gc * ldb : Bx + (long long)(gc - n_main) * ldb;
+            } else {
+                // k-major B: this piece holds k rows R - BM .. of the chunk, the lane its row (lane / 16) and physical slot lane % 16
+                const int kr = R - BM;                              // k row within the chunk: 4 (piece) + lane / 16
+                int gn = n0 + 4 * ((lane & 15) ^ (((kr >> 2) & 3) << 2));
+                gn = gn + 3 < N ? gn : N - 4;                       // quads past the matrix re-read valid columns (never stored)
+                src[j] = B + (long long)kr * ldb + gn;              // (+ chunk row offset at issue time)
+                continue;
             }
             src[j] = p + 4 * kq;
         }
@@ -154,9 +167,11 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
             float *dst0 = gemm_lds + stage * STAGE + wave * 256;
             if (kn + 64 <= K) {                                     // workgroup-uniform
 #pragma unroll
-                for (int j = 0; j < NPW; ++j)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + kn),
+                for (int j = 0; j < NPW; ++j) {
+                    const bool brow = BKM && 4 * (wave + 4 * j) >= BM;     // a k-major B piece: the chunk is kn ROWS further down
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + (brow ? (long long)kn * ldb : (long long)kn)),
                                                      (__attribute__((address_space(3))) void *)(dst0 + j * 1024), 16, 0, 0);
+                }
             } else {
                 // a short last chunk (K % 64 != 0): quads past K re-read quad 0 of the chunk (those k-blocks are skipped)
 #pragma unroll
@@ -164,6 +179,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
                     const int R = 4 * (wave + 4 * j) + (lane >> 4);
                     const int kq = kq_base ^ (R & 15);
                     const float *g = src[j] + kn - ((kn + 4 * kq + 4 <= K) ? 0 : 4 * kq);
+                    if (BKM && 4 * (wave + 4 * j) >= BM) {          // k-major B piece: rows past K re-read the last row (skipped k-blocks)
+                        const int kr = R - BM;
+                        g = src[j] + (long long)(kn + kr < K ? kn : K - 1 - kr) * ldb;
+                    }
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                                      (__attribute__((address_space(3))) void *)(dst0 + j * 1024), 16, 0, 0);
                 }
@@ -200,8 +219,14 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
     } else {
         // ---- computing waves
         const int boff = (BM + 16 * BC * wave + r) * 64, aoff = r * 64;
+        // (k-major B: element t of the operand = row 16 d + 4 q + t of the [64 k][64 n] tile, slot (n / 4) ^ 4 q, element n % 4)
+        const int bkoff = BM * 64 + 4 * (((16 * wave + r) >> 2) ^ (q << 2)) + (r & 3) + 4 * q * 64;
         auto frags = [&](const float *st, int d, f32x4 (&bv)[BC], f32x4 (&av)[ACC]) {
             const int slot = 4 * ((4 * d + q) ^ r);
+            if (BKM) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[0][t] = st[bkoff + (16 * d + t) * 64];
+            } else
 #pragma unroll
             for (int g = 0; g < BC; ++g) bv[g] = *reinterpret_cast<const f32x4 *>(&st[boff + g * 1024 + slot]);
 #pragma unroll
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const float *__restrict_
 // One configuration of gemm_glds_kernel.  Above 64 KB of dynamic LDS a kernel has to be opted in, and the attribute is
 // per DEVICE: one atomic per (instantiation, device) -- 0 not tried, 1 opted in, 2 refused.  Returns false when the
 // configuration cannot run here (the caller then takes gemm_nt_kernel: same results, bit for bit).
-template <int ACC, int EPI, int NST = 3, int BC = 1>
+template <int ACC, int EPI, int NST = 3, int BC = 1, bool BKM = false>
 bool launch_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, int ldb, const float *Bx, int M, int N,
                      int n_main, int K, float *C, int ldc, const GemmEpi &ep)
 {
@@ -357,14 +382,14 @@ bool launch_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, in
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
         int s = opted[dev].load(std::memory_order_acquire);
         if (s == 0) {
-            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<ACC, EPI, NST, BC>),
+            s = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<ACC, EPI, NST, BC, BKM>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 2;
             opted[dev].store(s, std::memory_order_release);
         }
         if (s != 1) return false;
     }
     const dim3 grid((N + 64 * BC - 1) / (64 * BC), (M + 16 * ACC - 1) / (16 * ACC));
-    hipLaunchKernelGGL((gemm_glds_kernel<ACC, EPI, NST, BC>), grid, dim3(512), lds, st, A, lda, B, ldb, Bx, M, N, n_main, K, C,
+    hipLaunchKernelGGL((gemm_glds_kernel<ACC, EPI, NST, BC, BKM>), grid, dim3(512), lds, st, A, lda, B, ldb, Bx, M, N, n_main, K, C,
                        ldc, ep);
     return true;
 }
@@ -377,12 +402,12 @@ bool launch_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, in
 // (252 of them): measured 26.1 us against 26.5 for two rounds of 128 x 64 -- and 64 + 80 accumulator and operand registers
 // plus the compiler's copies do not fit 256: the instantiation spilled inside the loop, so it is not offered
 // (tests/test_abi_cpu.py::test_glds_gemm_code_objects holds every instantiation to 0 B of scratch).  Returns ACC + 16 (BC - 1).
-inline int glds_pick_tile(int M, int N, int K)
+inline int glds_pick_tile(int M, int N, int K, int max_bc = 2)
 {
     const long long nch = (K + 63) / 64;
     int best = 1;
     long long best_cost = -1;
-    for (int bc = 1; bc <= 2; ++bc) {
+    for (int bc = 1; bc <= max_bc; ++bc) {
         const long long ncb = (N + 64 * bc - 1) / (64 * bc);
         for (int a = 1; a <= (bc == 1 ? 8 : 7); ++a) {             // 128 x 128 tiles (a = 8, bc = 2) do not fit 256 registers: they spill
             const long long tiles = ncb * ((M + 16 * a - 1) / (16 * a));
@@ -414,3 +439,20 @@ bool launch_glds(hipStream_t st, const float *A, int lda, const float *B, int ld
     return false;
 }
 
+
+// C = A * B for a K-MAJOR B (B[k * ldb + n]): the dX = dY W products of the training backward, no transposed copy of the weight
+// (EPI 2: plain / accumulating store).  false: the operands do not fit (the caller transposes and takes launch_glds).
+inline bool launch_glds_bkm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C,
+                            int ldc, const GemmEpi &ep)
+{
+    if ((lda & 3) || (ldb & 3) || (N & 3) || N < 4 || (K & 15) || (reinterpret_cast<unsigned long long>(A) & 15) ||
+        (reinterpret_cast<unsigned long long>(B) & 15))
+        return false;
+#define NSC_GLDS_BKM_CASE(a) case a: return launch_glds_cfg<a, 2, 3, 1, true>(st, A, lda, B, ldb, nullptr, M, N, N, K, C, ldc, ep);
+    switch (glds_pick_tile(M, N, K, 1)) {
+        NSC_GLDS_BKM_CASE(1) NSC_GLDS_BKM_CASE(2) NSC_GLDS_BKM_CASE(3) NSC_GLDS_BKM_CASE(4)
+        NSC_GLDS_BKM_CASE(5) NSC_GLDS_BKM_CASE(6) NSC_GLDS_BKM_CASE(7) NSC_GLDS_BKM_CASE(8)
+    }
+#undef NSC_GLDS_BKM_CASE
+    return false;
+}

@@ -324,7 +324,8 @@ class GNNTrainer:
                 self._seen_once.add(key)                    # first batch of this shape runs eagerly (lazy set-up, warm-up)
                 return None
             try:
-                idx = [torch.empty(T, dtype=torch.int64, device=dev) for _ in range(3)]
+                idx_all = torch.empty((3, T), dtype=torch.int64, device=dev)      # one static buffer: one copy per batch feeds it
+                idx = [idx_all[0], idx_all[1], idx_all[2]]
                 seed = torch.zeros(1, dtype=torch.int64, device=dev)
                 self._ensure_flat_grads(params)             # static gradient storage
                 for p in params:
@@ -338,7 +339,7 @@ class GNNTrainer:
                     loss = self._eager_step(graph, idx[0], idx[1], idx[2], scale)
                 # the entry keeps what the capture baked in alive (CSR arrays, graph tensors): while it exists their ids
                 # and addresses in the key cannot be recycled
-                ent = (cg, idx, seed, loss, [p.grad for p in params], (csr, graph, ea))
+                ent = (cg, idx, seed, loss, [p.grad for p in params], (csr, graph, ea), idx_all)
                 self._captured[key] = ent
                 while len(self._captured) > self.max_captures:
                     self._captured.popitem(last=False)      # least recently used capture: graph + pool are dropped
@@ -361,11 +362,9 @@ class GNNTrainer:
         n = int(graph.x.shape[0])
         if h.size and (h.min() < -n or h.max() >= n):
             raise IndexError(f"triplet index out of range for {n} embeddings")
-        for j in range(3):
-            # bt_dev: the batch's (3, T) index rows already on the device (train_batches uploads an epoch's triplets once:
-            # a per-batch copy from pageable host memory would block the host until the stream has drained)
-            idx[j].copy_(bt_dev[j] if bt_dev is not None else torch.from_numpy(np.ascontiguousarray(h[:, j])),
-                         non_blocking=True)
+        # bt_dev: the batch's (3, T) index rows already on the device (train_batches uploads an epoch's triplets once: a
+        # per-batch copy from pageable host memory would block the host until the stream has drained); ONE copy for the three rows
+        ent[6].copy_(bt_dev if bt_dev is not None else torch.from_numpy(np.ascontiguousarray(h.T)), non_blocking=True)
         seed.fill_(int(torch.randint(0, 2 ** 62, (1,)).item()) if float(getattr(inner, "dropout", 0.0)) > 0 else 0)
         cg.replay()                                         # (num_batches_tracked is incremented inside the capture)
         return loss.detach().clone()

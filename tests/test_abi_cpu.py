@@ -211,9 +211,43 @@ def test_glds_gemm_code_objects(lib, tmp_path):
             assert not [t for t in ins if re.match(r"ds_write(2)?_b(64|96|128)", t)], f"{name}: wide ds_write (register staging crept in)"
             # the staging waves' counted wait survives: vmcnt(N > 0) directly in front of a raw s_barrier
             counted = [i for i, t in enumerate(ins) if re.match(r"s_waitcnt vmcnt\([1-9]\d*\)$", t) and ins[i + 1].startswith("s_barrier")]
-            if "ELi3ELi1EE" in name:                           # three stages: one chunk stays in flight across the barrier
+            if "ELi3ELi1ELb" in name:                          # three stages: one chunk stays in flight across the barrier
                 assert counted, f"{name}: no counted vmcnt wait in front of a barrier"
     assert seen >= 45, seen                                   # (8 + 7) tiles x 3 epilogues
+
+
+def test_round4_kernels_code_objects(lib, tmp_path):
+    """gat_layer_banded_kernel (640 threads: three waves on two SIMDs -> at most 168 registers per lane) and
+    gemm_tn_glds_kernel (512 threads): no scratch, staging by LDS-DMA only, MFMAs present, and the staging waves' counted wait
+    (`s_waitcnt vmcnt(N > 0)` directly followed by a raw `s_barrier`) survives the compiler."""
+    llvm, objs = _code_objects(tmp_path)
+    seen = {"gat_layer_banded_kernel": 0, "gemm_tn_glds_kernel": 0}
+    for f in objs:
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", f], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split(".agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            kind = next((k for k in seen if name and k in name.group(1)), None)
+            if kind is None:
+                continue
+            ag = int(re.match(r":\s+(\d+)", blk).group(1))
+            vg = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+            sc = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+            cap = 168 if kind == "gat_layer_banded_kernel" else 256
+            assert vg + ag <= cap and sc == 0, f"{name.group(1)}: {vg} VGPRs (+{ag} AGPRs), {sc} B scratch"
+            seen[kind] += 1
+        dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", f], check=True, capture_output=True,
+                             text=True).stdout
+        for m in re.finditer(r"^[0-9a-f]+ <(\S*(?:gat_layer_banded_kernel|gemm_tn_glds_kernel)\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis,
+                             flags=re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.strip()]
+            assert [t for t in ins if t.startswith("global_load_lds_dwordx4")] and [t for t in ins if t.startswith("v_mfma_f32_16x16x4")], name
+            assert not [t for t in ins if re.match(r"ds_write(2)?_b(96)", t)], name
+            counted = [i for i, t in enumerate(ins) if re.match(r"s_waitcnt vmcnt\([1-9]\d*\)$", t) and ins[i + 1].startswith("s_barrier")]
+            assert counted, f"{name}: no counted vmcnt wait in front of a barrier"
+            if "gat_layer_banded_kernel" in name:              # the attention chains: u broadcast by v_readlane, the softmax by DPP
+                assert [t for t in ins if t.startswith("v_readlane_b32")] and [t for t in ins if "row_ror:8" in t or "row_half_mirror" in t], name
+    assert seen["gat_layer_banded_kernel"] == 6 and seen["gemm_tn_glds_kernel"] == 1, seen
 
 
 def test_stream_loop_isa(lib, tmp_path):

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(640) void gat_layer_banded_kernel(BandArgs a, const
     const f32x4 bnsh = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 64 + 4 * s16]);
     const f32x4 bnbi = *reinterpret_cast<const f32x4 *>(&Cs[O_BN + 128 + 4 * s16]);
     float al_[NPASS];
-    int jl_[NPASS];
+    int jl_[NPASS], dw_[NPASS];
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         const int lo = pass * NG + grp, i = own0 + lo;
@@ -369,22 +369,37 @@ __global__ __launch_bounds__(640) void gat_layer_banded_kernel(BandArgs a, const
         if (a.alpha_out && valid && live && n0 == 0) a.alpha_out[eidx] = al;
         al_[pass] = al;
         jl_[pass] = jl;
+        // entries of the fullest of this wave's four targets (valid slots are a prefix of the 8): the aggregation below stops
+        // there -- on the temporal chain 5 of the 8 slots, and this phase is bound by the LDS pipe (ten waves gathering rows)
+        const unsigned long long vm = __ballot(valid);
+        int dmax = 0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) dmax = max(dmax, __popc((unsigned)(vm >> (16 * g4)) & 0xffffu));
+        dw_[pass] = __builtin_amdgcn_readfirstlane(dmax);
+    }
+    // the passes' gathers interleaved slot by slot (independent chains of a cross-lane broadcast, an LDS row read and four fmas)
+    f32x4 o_[NPASS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) o_[pass] = zero;
+#pragma unroll
+    for (int t = 0; t < ((NSC_BAND_ABL & 1) ? 1 : SLOTS); ++t) {   // entries in CSR order, self loop last
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (t >= dw_[pass]) continue;                          // wave-uniform: the remaining slots carry weight 0 (x + 0 * h = x)
+            const float at = __shfl(al_[pass], t, 16);
+            const int jt = __shfl(jl_[pass], t, 16);
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&Cs[jt * LD + 4 * s16]);
+            o_[pass].x = __builtin_fmaf(at, gv.x, o_[pass].x);
+            o_[pass].y = __builtin_fmaf(at, gv.y, o_[pass].y);
+            o_[pass].z = __builtin_fmaf(at, gv.z, o_[pass].z);
+            o_[pass].w = __builtin_fmaf(at, gv.w, o_[pass].w);
+        }
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         const int lo = pass * NG + grp, i = own0 + lo;
         const bool live = lo < OWN && i < M;
-        f32x4 o = zero;
-#pragma unroll
-        for (int t = 0; t < ((NSC_BAND_ABL & 1) ? 1 : SLOTS); ++t) {   // entries in CSR order, self loop last
-            const float at = __shfl(al_[pass], t, 16);
-            const int jt = __shfl(jl_[pass], t, 16);
-            const f32x4 gv = *reinterpret_cast<const f32x4 *>(&Cs[jt * LD + 4 * s16]);
-            o.x = __builtin_fmaf(at, gv.x, o.x);
-            o.y = __builtin_fmaf(at, gv.y, o.y);
-            o.z = __builtin_fmaf(at, gv.z, o.z);
-            o.w = __builtin_fmaf(at, gv.w, o.w);
-        }
+        f32x4 o = o_[pass];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float v = o[t] + bnbi[t];

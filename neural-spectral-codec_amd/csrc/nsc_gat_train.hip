@@ -202,40 +202,49 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 // across it, split over K slabs
 // (blockIdx.z) whose sums slab_reduce_kernel adds in fixed order: deterministic.  k order of every output element: ascending.
 // ---------------------------------------------------------------------------------------------
+template <int TM>   // tile (64 TM) x 64: TM = 2 for the wide products (a computing wave owns a 64 x 32 tile: eight accumulators)
 __global__ __launch_bounds__(512) void gemm_tn_glds_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
                                                            int ldb, int M, int N, int K, int kslab,
                                                            float *__restrict__ slabs, long long slab)
 {
-    constexpr int NST = 3, STAGE = 2 * 64 * 64;                    // floats per stage: A tile [64 k][64 m] | B tile [64 k][64 n]
+    constexpr int BM = 64 * TM, NST = 3, STAGE = 64 * BM + 64 * 64;   // floats per stage: A tile [64 k][BM m] | B tile [64 k][64 n]
+    constexpr int SA = 16 * TM;                                    // 16-byte slots per A row; a 1 KiB piece = 64 / SA rows
+    constexpr int PA = 64 * SA / 64, NPW = (PA + 16) / 4;          // A pieces per chunk (+ 16 B pieces), pieces per staging wave
     extern __shared__ __attribute__((aligned(1024))) float tn_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave8 & 3;
     const int r = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 64;
     const int k0 = blockIdx.z * kslab, k1 = min(K, k0 + kslab);
     const int nchunks = (k1 - k0 + 63) >> 6;
     if (nchunks <= 0) return;                                       // (cannot happen: the host trims empty slabs)
 
     if (wave8 >= 4) {
         // ---- staging waves (wave specialisation as in gemm_glds_kernel: an LDS-DMA instruction costs its wave 60-185 cycles of
-        // issue; with the 8 per chunk in the computing waves' own stream the first form of this kernel took 17.6 us per product):
-        // piece p of a chunk = 4 k rows of one tile (1 KiB, lane-linear); 32 pieces per chunk, wave w takes pieces w, w + 4, ...
-        // (pieces 0-15: A rows 4 p .. 4 p + 3, pieces 16-31: B rows)
-        const int kq = lane >> 4, slot = lane & 15;                 // row within the piece, physical 16-byte slot within the row
-        const int mq = slot ^ (kq << 2);                            // logical quad held by that slot: (4 p + kq) mod 4 = kq
-        int ma = m0 + 4 * mq, nb = n0 + 4 * mq;
-        ma = ma + 3 < M ? ma : M - 4;                               // quads past the matrix re-read valid columns: their products only
-        nb = nb + 3 < N ? nb : N - 4;                               // reach outputs that are never stored
-        const float *srcA = A + ma, *srcB = B + nb;
+        // issue; with them in the computing waves' own stream the first form of this kernel took 17.6 us per product): piece p of a
+        // chunk = 1 KiB, lane-linear: 64 / SA rows of the A tile (p < PA) or 4 rows of the B tile; wave w takes pieces w, w + 4, ...
         auto issue = [&](int ch, int stage) {
             float *dst = tn_lds + stage * STAGE + wave * 256;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NPW; ++j) {
                 const int p = wave + 4 * j;                        // uniform
-                int k = k0 + (ch << 6) + 4 * (p & 15) + kq;
-                k = k < K ? k : K - 1;                              // rows past K re-read the last row: masked out of the products
-                const float *g = (p < 16) ? srcA + (long long)k * lda : srcB + (long long)k * ldb;
+                const float *g;
+                if (p < PA) {
+                    const int row = (64 / SA) * p + lane / SA, slot = lane % SA;
+                    int ma = m0 + 4 * (slot ^ ((row & 3) << 2));    // the slot holds quad slot ^ 4 (k mod 4)
+                    ma = ma + 3 < M ? ma : M - 4;                   // quads past the matrix re-read valid columns (never stored)
+                    int k = k0 + (ch << 6) + row;
+                    k = k < K ? k : K - 1;                          // rows past K re-read the last row: masked out of the products
+                    g = A + (long long)k * lda + ma;
+                } else {
+                    const int row = 4 * (p - PA) + (lane >> 4), slot = lane & 15;
+                    int nb = n0 + 4 * (slot ^ ((row & 3) << 2));
+                    nb = nb + 3 < N ? nb : N - 4;
+                    int k = k0 + (ch << 6) + row;
+                    k = k < K ? k : K - 1;
+                    g = B + (long long)k * ldb + nb;
+                }
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                                  (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
             }
@@ -243,24 +252,26 @@ __global__ __launch_bounds__(512) void gemm_tn_glds_kernel(const float *__restri
         issue(0, 0);
         if (1 < nchunks) issue(1, 1);
         for (int c = 0; c < nchunks; ++c) {
-            if (c + 1 < nchunks) glds_wait_barrier<8>();           // chunk c landed (this wave's 8 pieces of chunk c + 1 may fly on)
+            if (c + 1 < nchunks) glds_wait_barrier<NPW>();         // chunk c landed (this wave's pieces of chunk c + 1 may fly on)
             else glds_wait_barrier<0>();
             if (c + 2 < nchunks) issue(c + 2, (c + 2) % NST);       // its stage held chunk c - 1: every computing wave is past that
         }
         return;
     }
 
-    // ---- computing waves: 2 x 2, a 32 x 32 tile each
+    // ---- computing waves: 2 x 2, a (32 TM) x 32 tile each
+    constexpr int NI = 2 * TM;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[2][2] = {{zero, zero}, {zero, zero}};
-    const int wm = wave >> 1, wn = wave & 1;
-    // operand addresses inside a stage (floats): row k = 4 s + q -> + (4 s + q) * 64; quad (8 wm + 4 mi + r / 4) ^ (4 q), element r % 4
-    int offA[2], offB[2];
+    f32x4 acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        offA[i] = q * 64 + 4 * ((8 * wm + 4 * i + (r >> 2)) ^ (q << 2)) + (r & 3);
-        offB[i] = 64 * 64 + q * 64 + 4 * ((8 * wn + 4 * i + (r >> 2)) ^ (q << 2)) + (r & 3);
-    }
+    for (int i = 0; i < NI; ++i) acc[i][0] = acc[i][1] = zero;
+    const int wm = wave >> 1, wn = wave & 1;
+    // operand addresses inside a stage (floats): row k = 4 s + q -> + (4 s + q) * row length; quad (m / 4) ^ (4 q), element r % 4
+    int offA[NI], offB[2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) offA[i] = q * BM + 4 * ((8 * TM * wm + 4 * i + (r >> 2)) ^ (q << 2)) + (r & 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offB[i] = 64 * BM + q * 64 + 4 * ((8 * wn + 4 * i + (r >> 2)) ^ (q << 2)) + (r & 3);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_barrier" ::: "memory");                    // barrier c: chunk c has landed, chunk c - 1 is read
         const float *st = tn_lds + (c % NST) * STAGE;
@@ -268,22 +279,26 @@ __global__ __launch_bounds__(512) void gemm_tn_glds_kernel(const float *__restri
         if (kleft >= 64) {
 #pragma unroll
             for (int s4 = 0; s4 < 16; ++s4) {
-                float a[2], b[2];
+                float a[NI], b[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { a[i] = st[offA[i] + s4 * 256]; b[i] = st[offB[i] + s4 * 256]; }
+                for (int i = 0; i < NI; ++i) a[i] = st[offA[i] + s4 * 4 * BM];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) b[i] = st[offB[i] + s4 * 256];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
             for (int s4 = 0; 4 * s4 < kleft; ++s4) {                // the slab's last, short chunk: k rows past the end count as zero
                 const bool in = 4 * s4 + q < kleft;
-                float a[2], b[2];
+                float a[NI], b[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { a[i] = in ? st[offA[i] + s4 * 256] : 0.0f; b[i] = in ? st[offB[i] + s4 * 256] : 0.0f; }
+                for (int i = 0; i < NI; ++i) a[i] = in ? st[offA[i] + s4 * 4 * BM] : 0.0f;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) b[i] = in ? st[offB[i] + s4 * 256] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
@@ -291,48 +306,60 @@ __global__ __launch_bounds__(512) void gemm_tn_glds_kernel(const float *__restri
     }
     float *Cz = slabs + (long long)blockIdx.z * slab;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + 32 * wn + 16 * j + r;
             if (col >= N) continue;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {                    // C/D layout: column = lane & 15, row = (lane >> 4) * 4 + reg
-                const int row = m0 + 32 * wm + 16 * i + 4 * q + reg;
+                const int row = m0 + 32 * TM * wm + 16 * i + 4 * q + reg;
                 if (row < M) Cz[(long long)row * N + col] = acc[i][j][reg];
             }
         }
 }
 
 // dW = A^T B over K slabs on gemm_tn_glds_kernel; false when the operands do not fit it (the caller takes gemm_gen_kernel)
-bool launch_tn_glds(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C,
-                    int accumulate, float *slabs, int max_slabs)
+template <int TM>
+bool launch_tn_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C,
+                        int accumulate, float *slabs, int max_slabs)
 {
-    if ((lda & 3) || (ldb & 3) || M < 4 || N < 4 || (M & 3) || (N & 3) || K < 1 || !slabs || (reinterpret_cast<unsigned long long>(A) & 15) ||
-        (reinterpret_cast<unsigned long long>(B) & 15))
-        return false;
-    constexpr unsigned lds = 3 * 2 * 64 * 64 * 4;                  // 96 KB: above 64 KB a kernel is opted in, per device
+    constexpr unsigned lds = 3 * (64 * 64 * TM + 64 * 64) * 4;     // 96 / 144 KB: above 64 KB a kernel is opted in, per device
     static std::atomic<int> opted[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
     int o = opted[dev].load(std::memory_order_acquire);
     if (o == 0) {
-        o = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        o = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_glds_kernel<TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) == hipSuccess ? 1 : 2;
         opted[dev].store(o, std::memory_order_release);
     }
     if (o != 1) return false;
-    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    const int tiles = ((M + 64 * TM - 1) / (64 * TM)) * ((N + 63) / 64);
     int splits = 256 / tiles;                                       // about one round of workgroups on the 256 CUs
     splits = splits < 1 ? 1 : (splits > max_slabs ? max_slabs : splits);
     int kslab = (K + splits - 1) / splits;
     kslab = (kslab + 63) / 64 * 64;
     splits = (K + kslab - 1) / kslab;                               // no empty slab
     const long long MN = (long long)M * N;
-    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(512), lds, st, A, lda, B, ldb, M, N, K,
-                       kslab, slabs, MN);
+    hipLaunchKernelGGL(gemm_tn_glds_kernel<TM>, dim3((N + 63) / 64, (M + 64 * TM - 1) / (64 * TM), splits), dim3(512), lds, st, A, lda, B,
+                       ldb, M, N, K, kslab, slabs, MN);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
     return true;
+}
+
+bool launch_tn_glds(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C,
+                    int accumulate, float *slabs, int max_slabs)
+{
+    if ((lda & 3) || (ldb & 3) || M < 4 || N < 4 || (M & 3) || (N & 3) || K < 1 || !slabs ||
+        (reinterpret_cast<unsigned long long>(A) & 15) || (reinterpret_cast<unsigned long long>(B) & 15))
+        return false;
+    // the wide products (800 x 256 / 256 x 800: 52 tiles of 64 x 64 x 4 slabs would leave 48 CUs idle) take 128 x 64 tiles:
+    // 28 / 26 tiles x 9 slabs = one round of 252 / 234 workgroups
+    if (((M + 63) / 64) * ((N + 63) / 64) >= 40 && M >= 128 &&
+        launch_tn_glds_cfg<2>(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, max_slabs))
+        return true;
+    return launch_tn_glds_cfg<1>(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, max_slabs);
 }
 
 // ---------------------------------------------------------------------------------------------

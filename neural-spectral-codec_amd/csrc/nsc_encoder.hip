@@ -29,6 +29,8 @@
 
 namespace {
 
+#include "nsc_fill.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -1465,7 +1467,7 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
     } else {
         const size_t need = (size_t)n_clouds * d.E * A * sizeof(unsigned);
         if (!ws || ws_bytes < need) return NSC_EWORKSPACE;
-        if (hipMemsetAsync(ws, 0xff, need, stream) != hipSuccess) return NSC_ELAUNCH;
+        nsc_fill_u32(stream, ws, 0xffffffffu, (long long)(need / 4));
         auto ks = scatter_split_kernel<FUSED_NW, FUSED_U>;
         const int img_bytes = d.E * A * 4;
         if ((st = set_lds(ks, img_bytes)) != NSC_OK) return st;
@@ -1492,7 +1494,7 @@ int nsc_project_intensity(const float *pts, const int64_t *cloud_offsets, int32_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const EncDev d = make_dev(p, p->n_elevation);
     const int npix = d.E * A;
-    if (hipMemsetAsync(out_intensity, 0, (size_t)n_clouds * npix * sizeof(float), stream) != hipSuccess) return NSC_ELAUNCH;
+    nsc_fill_u32(stream, out_intensity, 0u, (long long)n_clouds * npix);
     int parts = 1;
     if (n_clouds < 1024) {                       // fill the chip when the batch is small
         const long long avg = total_points / n_clouds;
@@ -1521,7 +1523,7 @@ int nsc_scatter_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n
     const long long *off = reinterpret_cast<const long long *>(cloud_offsets);
     const int img_bytes = d.E * A * 4;
     if (parts > 1) {
-        if (hipMemsetAsync(out_sqr, 0xff, (size_t)n_clouds * img_bytes, stream) != hipSuccess) return NSC_ELAUNCH;
+        nsc_fill_u32(stream, out_sqr, 0xffffffffu, (long long)n_clouds * (img_bytes / 4));
         auto ks = scatter_split_kernel<FUSED_NW, FUSED_U>;
         if ((st = set_lds(ks, img_bytes)) != NSC_OK) return st;
         hipLaunchKernelGGL(ks, dim3(n_clouds * parts), dim3(FUSED_NW * 64), img_bytes, stream, pts, off, stride, parts,

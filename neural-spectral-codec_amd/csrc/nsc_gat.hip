@@ -30,6 +30,7 @@ namespace {
 
 #include "nsc_gemm_glds.h"
 #include "nsc_gat_banded.h"
+#include "nsc_fill.h"
 
 // ---------------------------------------------------------------------------------------------
 // CSR build
@@ -998,7 +999,7 @@ int nsc_graph_build_csr(const int64_t *edge_index, int64_t E, int32_t N, const f
     hipStream_t st = static_cast<hipStream_t>(stream_);
     int *deg = static_cast<int *>(ws);
     int *cursor = reinterpret_cast<int *>(static_cast<char *>(ws) + need / 2);
-    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return NSC_ELAUNCH;
+    nsc_fill_u32(st, ws, 0u, (long long)(need / 4));
     const long long *ei = reinterpret_cast<const long long *>(edge_index);
     long long blocks = (E + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -1022,7 +1023,7 @@ int nsc_graph_band_entries(const NscGraph *g, const float *edge_attr, int32_t ed
     if (edge_attr && edge_dim > 0 && !g->loop_attr) return NSC_EINVAL;
     if (reinterpret_cast<unsigned long long>(entries) & 15) return NSC_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    if (hipMemsetAsync(info, 0, 2 * sizeof(int32_t), st) != hipSuccess) return NSC_ELAUNCH;
+    nsc_fill_u32(st, info, 0u, 2);
     hipLaunchKernelGGL(band_entries_kernel, dim3((g->n_nodes + 255) / 256), dim3(256), 0, st, g->row_ptr, g->src, g->eid,
                        (edge_dim > 0) ? edge_attr : nullptr, edge_dim, g->loop_attr, g->n_nodes,
                        reinterpret_cast<f32x4 *>(entries), info);

@@ -24,6 +24,7 @@
 namespace {
 
 #include "nsc_gemm_glds.h"
+#include "nsc_fill.h"
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -694,6 +695,29 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float *__restrict__ z
         for (int u = 0; u < 8; ++u) step(n + 4 * u, z8[u], r8[u]);
     }
     for (; n < n1; n += 4) step(n, z[(long long)n * C + c], resid ? resid[(long long)n * C + c] : 0.0f);
+}
+
+// Zero fill / copy as KERNELS (round 4).  The training step is replayed as a captured hipGraph, and a hipMemsetAsync captured into
+// a graph becomes a memset NODE: in replays on ROCm 7.2 the node that zeroes the triplet gradient was observed not to be ordered
+// before the kernel that accumulates into it -- the embedding gradient then starts from whatever the graph's pool holds (sums of
+// 1e25-1e32 in the parameter gradients, differently in every run; Adam's normalisation hid it from every +-lr parameter check:
+// tests/test_a_multirank_gpu.py::test_data_parallel_captured_step_replays_under_a_process_group and
+// test_captured_step_gradients_match_eager now compare the gradients themselves).  Kernel nodes keep their stream order.
+__global__ __launch_bounds__(256) void fill_zero_kernel(float *__restrict__ p, long long n)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<f32x4 *>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    else
+        for (long long j = i; j < n; ++j) p[j] = 0.0f;
+}
+__global__ __launch_bounds__(256) void copy_kernel(float *__restrict__ dst, const float *__restrict__ src, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+inline void fill_zero(hipStream_t st, float *p, long long n)
+{
+    if (n > 0) hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, p, n);
 }
 
 __global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b,
@@ -1449,7 +1473,7 @@ int nsc_graph_transpose(const NscGraph *g, int32_t *t_ptr, int32_t *t_entry, int
     hipStream_t st = static_cast<hipStream_t>(stream_);
     int *cnt = static_cast<int *>(ws);
     int *cursor = reinterpret_cast<int *>(static_cast<char *>(ws) + need / 2);
-    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return NSC_ELAUNCH;
+    nsc_fill_u32(st, ws, 0u, (long long)(need / 4));
     hipLaunchKernelGGL(tcsr_count_kernel, dim3(blocks(N)), dim3(256), 0, st, g->row_ptr, g->src, N, cnt, tgt);
     hipLaunchKernelGGL(tcsr_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, N, t_ptr);
     hipLaunchKernelGGL(tcsr_fill_kernel, dim3(blocks(N)), dim3(256), 0, st, g->row_ptr, g->src, N, t_ptr, cursor, t_entry);
@@ -1576,11 +1600,11 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         // gradient wrt the input features through the residual connection: dOut itself (identity residual),
         // dOut W_res (residual_proj) or nothing (residual=False); dZ0 W_in is accumulated at the end
         if (res_id) {
-            if (hipMemcpyAsync(gr->x, grad_out, (size_t)N * Din * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return NSC_ELAUNCH;
+            hipLaunchKernelGGL(copy_kernel, dim3(blocks((long long)N * Din)), dim3(256), 0, st, gr->x, grad_out, (long long)N * Din);
         } else if (res_proj) {
             gemm<false, true>(st, grad_out, Dout, m->res_w, Din, N, Din, Dout, gr->x, Din, nullptr, 0, 1, slabs);
         } else {
-            if (hipMemsetAsync(gr->x, 0, (size_t)N * Din * 4, st) != hipSuccess) return NSC_ELAUNCH;
+            fill_zero(st, gr->x, (long long)N * Din);
         }
     }
 
@@ -1637,8 +1661,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
                 hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(1), dim3(256), 0, st, colpart, EDGE_BWD_WGS, Ly.lin_edge_w, Ly.att_edge,
                                    H, m->edge_dim, Gl.lin_edge_w, Gl.att_edge, acc);
             } else if (!acc) {                      // no edge term in this forward: zero gradient (nothing to add when accumulating)
-                if (hipMemsetAsync(Gl.lin_edge_w, 0, (size_t)H * m->edge_dim * 4, st) != hipSuccess) return NSC_ELAUNCH;
-                if (hipMemsetAsync(Gl.att_edge, 0, (size_t)H * 4, st) != hipSuccess) return NSC_ELAUNCH;
+                fill_zero(st, Gl.lin_edge_w, (long long)H * m->edge_dim);
+                fill_zero(st, Gl.att_edge, H);
             }
         }
         // g = h_l W^T :  dW = dG^T h_l ,  dh_l = dG W (+ residual path)
@@ -1667,8 +1691,11 @@ int nsc_triplet_loss(const float *emb, const int64_t *anchors, const int64_t *po
     if (T < 0 || N < 0 || D < 1 || (T > 0 && N == 0)) return NSC_EINVAL;
     if (!loss) return NSC_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    if (grad_emb && hipMemsetAsync(grad_emb, 0, (size_t)N * D * 4, st) != hipSuccess) return NSC_ELAUNCH;
-    if (T == 0) return hipMemsetAsync(loss, 0, 4, st) == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+    if (grad_emb) fill_zero(st, grad_emb, (long long)N * D);
+    if (T == 0) {
+        fill_zero(st, loss, 1);
+        return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
+    }
     if (!emb || !anchors || !positives || !negatives) return NSC_EINVAL;
     if (!ws || ws_bytes < nsc_triplet_workspace_bytes(T)) return NSC_EWORKSPACE;
     float *per = static_cast<float *>(ws);

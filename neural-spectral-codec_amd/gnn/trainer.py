@@ -274,7 +274,7 @@ class GNNTrainer:
         # the backward adds straight into the .grad tensors (they exist: zero_grad keeps them) -- no AccumulateGrad pass
         direct = (self.direct_grads and hasattr(inner, "_direct_grads")
                   and all(p.grad is not None for p in self.model.parameters() if p.requires_grad))
-        if direct and hasattr(inner, "train_step_direct") and self.model.training and all(
+        if direct and os.environ.get("NSC_TRAINER_NO_DIRECT") != "1" and hasattr(inner, "train_step_direct") and self.model.training and all(
                 isinstance(i, torch.Tensor) and i.is_cuda and i.dtype == torch.int64 for i in (ia, ip, in_)):
             # device-resident indices (the captured step's static buffers, an epoch's uploaded triplets): the three ABI calls
             # back to back, no autograd graph (round 4)

@@ -230,6 +230,57 @@ def test_data_parallel_train_step_through_hip_kernels(tmp_path):
 
 
 @pytest.mark.gpu
+def test_data_parallel_captured_step_replays_under_a_process_group(tmp_path):
+    """The captured training step under an initialised 2-rank group (advisor, round 3): 9 full batches of 128 triplets + a
+    ragged tail = three optimizer steps, so the capture (second full batch) is REPLAYED seven times between all-reduces;
+    forced on (`use_graph=True`: captures open in thread-local error mode) against off (the default under a > 1-rank group).
+    Both runs: identical parameters on the two ranks; graph vs eager: the same parameters up to Adam's +-lr on noise-only
+    elements; only full batches are captured (one capture, the tail runs eagerly)."""
+    tmp = str(tmp_path)
+
+    def run(tag, use_graph):
+        port = _free_port()
+        outs = [os.path.join(tmp, f"{tag}_r{r}.npz") for r in range(2)]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, TRAIN_WORKER, "--rank", str(r), "--world", "2", "--port", str(port), "--out", outs[r],
+                                   "--use-graph", str(use_graph), "--batches", "9", "--batch-size", "128"], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        logs = []
+        try:
+            for p in procs:
+                o, _ = p.communicate(timeout=600)
+                logs.append(o.decode(errors="replace")[-3000:])
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
+        for r, p in enumerate(procs):
+            assert p.returncode == 0, f"rank {r} of {tag} failed:\n{logs[r] if r < len(logs) else ''}"
+        return [np.load(o) for o in outs]
+
+    g = run("graph", 1)
+    e = run("eager", -1)
+    assert int(g[0]["captured"]) == 1 and int(g[1]["captured"]) == 1 and not int(g[0]["capture_failed"])
+    assert int(e[0]["captured"]) == 0                                  # the default under a 2-rank group: no capture
+    keys = [k[2:] for k in g[0].files if k.startswith("p:")]
+    lr = 5e-4
+    for k in keys:
+        assert np.array_equal(g[0]["p:" + k], g[1]["p:" + k]), f"{k}: ranks differ (captured)"
+        assert np.array_equal(e[0]["p:" + k], e[1]["p:" + k]), f"{k}: ranks differ (eager)"
+        assert np.isfinite(g[0]["p:" + k]).all()
+        # three Adam steps: an element whose gradient is rounding noise steps by +-lr per step on either side
+        assert np.abs(g[0]["p:" + k] - e[0]["p:" + k]).max() <= 6.3 * lr, k
+        # the gradients of the LAST optimizer step (after the all-reduce): finite, of the eager run's magnitude (round 4: a memset
+        # node of the captured graph left them at 1e25-1e32, which Adam's normalisation hid from the parameter check above)
+        ga, gb = e[0]["g:" + k], g[0]["g:" + k]
+        assert np.isfinite(gb).all() and np.abs(gb).max() <= 3.0 * np.abs(ga).max() + 1e-6, k
+    # the mean loss over the ten batches: after the first optimizer step the two runs' weights differ by +-lr on noise-only
+    # elements, the later batches' losses follow (measured: 3.7e-4 relative)
+    assert abs(float(g[0]["loss"]) - float(e[0]["loss"])) <= 2e-3 * abs(float(e[0]["loss"]))
+
+
+@pytest.mark.gpu
 def test_bench_launches_its_own_ranks(tmp_path):
     """``python bench.py --gpus 2`` with no WORLD_SIZE in the environment -- the shape of the driver's N = 1 command -- must
     run by itself: the parent starts two fresh ranks (it never initialises HIP), relays ONE well-formed line and exits 0.

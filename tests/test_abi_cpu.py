@@ -302,3 +302,17 @@ def test_bench_launcher_reports_a_failed_rank():
     assert p.returncode != 0
     assert b"[bench launcher]" in p.stderr
     assert p.stdout.strip() == b""
+
+
+def test_no_memset_or_memcpy_nodes_on_capturable_paths():
+    """Every entry point may be captured into a hipGraph (include/nsc.h).  A hipMemsetAsync captured into a graph becomes a memset
+    node, and round 4 found such a node (the zeroing of the triplet gradient) not ordered before the kernel after it in replays of
+    the captured training step: gradient sums of 1e25-1e32, hidden by Adam's normalisation from every +-lr parameter check.  The
+    library fills and copies with kernels (csrc/nsc_fill.h); this keeps it that way."""
+    import glob
+    src = glob.glob(os.path.join(ROOT, "neural-spectral-codec_amd", "csrc", "*.hip")) + glob.glob(
+        os.path.join(ROOT, "neural-spectral-codec_amd", "csrc", "*.h"))
+    assert src
+    for f in src:
+        code = re.sub(r"//[^\n]*", "", open(f).read())
+        assert "hipMemsetAsync" not in code and "hipMemcpyAsync" not in code and "hipMemset(" not in code, f

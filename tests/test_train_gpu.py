@@ -568,3 +568,45 @@ def test_in_kernel_gradient_accumulation_is_bit_exact(n, dropout):
         assert torch.equal(a0[k], d[k]), f"{k}: accumulate_grads = 1 into zeros differs from accumulate_grads = 0"
         assert torch.equal(d2[k], d[k] + d[k]), f"{k}: a second accumulating backward does not double the gradient"
         assert torch.isfinite(a0[k]).all()
+
+
+def test_captured_step_gradients_match_eager():
+    """What the +-lr parameter checks above cannot see (Adam normalises the gradient's magnitude away): the GRADIENTS the
+    optimizer is handed after four batches -- one issued eagerly and three replays of the captured step, then four replays -- must
+    equal the eagerly issued run's (same kernels; the triplet scatter's float atomics are the only difference) at every one of
+    three optimizer steps, and so must every batch's loss.  Round 4: a memset NODE in the captured graph (the zeroing of the
+    triplet gradient) was not ordered before the accumulating kernel in replays; the gradient sums reached 1e25-1e32."""
+    n = 1500
+    m0, g, _ = _setup(n, 2, seed=9)
+    rng = np.random.default_rng(4)
+    trip = np.stack([rng.integers(0, n, 9 * 128 + 37) for _ in range(3)], 1)
+    runs = []
+    for use_graph in (False, True):
+        m, g, _ = _setup(n, 2, seed=9)
+        tr = GNNTrainer(m, device="cuda", learning_rate=5e-4, weight_decay=1e-5, margin=0.1, batch_size=128, accumulation_steps=4,
+                        use_graph=use_graph)
+        seen, step = [], tr.optimizer.step
+        params = dict(m.gnn.named_parameters())
+
+        def hooked(*a, _seen=seen, _params=params, _step=step, **kw):
+            _seen.append({k: v.grad.detach().clone() for k, v in _params.items()})
+            return _step(*a, **kw)
+        tr.optimizer.step = hooked
+        loss = tr.train_batches(g, trip)
+        assert bool(tr._captured) == use_graph and not tr._capture_failed
+        runs.append((loss, seen))
+    (l0, s0), (l1, s1) = runs
+    assert len(s0) == len(s1) == 3
+    assert abs(l0 - l1) <= 1e-5 * abs(l0) + 1e-7
+    zero = {"input_proj.bias", "output_proj.bias", "batch_norms.2.bias"} | {f"convs.{l}.bias" for l in range(3)}
+    for step_no, (ga, gb) in enumerate(zip(s0, s1)):
+        scale = max(float(v.abs().max()) for v in ga.values())
+        for k in ga:
+            assert torch.isfinite(gb[k]).all(), (step_no, k)
+            ref = float(ga[k].abs().max())
+            d = float((ga[k] - gb[k]).abs().max())
+            if k in zero:                                   # exactly-zero gradients: rounding noise on both sides
+                assert ref < 1e-3 * scale and float(gb[k].abs().max()) < 1e-3 * scale, (step_no, k)
+                continue
+            # step 0: identical weights in both runs; later steps: the weights differ by +-lr on noise-only elements
+            assert d <= (2e-4 if step_no == 0 else 5e-2) * max(ref, 1e-6 * scale), (step_no, k, d, ref)

@@ -610,3 +610,36 @@ def test_captured_step_gradients_match_eager():
                 continue
             # step 0: identical weights in both runs; later steps: the weights differ by +-lr on noise-only elements
             assert d <= (2e-4 if step_no == 0 else 5e-2) * max(ref, 1e-6 * scale), (step_no, k, d, ref)
+
+
+def test_captured_graphs_hold_kernel_nodes_only():
+    """Round 4's bug class, checked structurally: a hipMemsetAsync / hipMemcpyAsync captured into a hipGraph becomes a memset /
+    memcpy NODE, and those are not ordered before the kernel node after them when the graph is replayed on ROCm 7.2.  Every
+    capture the package makes -- the training step (dropout on and off), the pipelined path's GNN forward -- must consist of
+    kernel nodes alone (tests/_hipgraph.py reads the node types back through the HIP runtime)."""
+    from _hipgraph import keep_graphs, node_types
+    from neural_spectral_codec_amd import distributed as nd, synth
+    from neural_spectral_codec_amd.encoding import SpectralEncoder
+    n = 600
+    rng = np.random.default_rng(4)
+    trip = np.stack([rng.integers(0, n, 4 * 128) for _ in range(3)], 1)
+    with keep_graphs() as made:
+        for dropout in (0.0, 0.1):
+            m, g, _ = _setup(n, 2, dropout=dropout, seed=9)
+            tr = GNNTrainer(m, device="cuda", learning_rate=5e-4, batch_size=128, accumulation_steps=2, use_graph=True)
+            tr.train_batches(g, trip)
+            assert tr._captured and not tr._capture_failed
+        n_train = len(made)
+        enc = SpectralEncoder(n_elevation=16).to("cuda")
+        m, _, _ = _setup(96, 2, seed=3)
+        m.eval()
+        piped = nd.ShardedDescriptorPath(enc, m, 96, synth.make_pose_chain(96, 0), pipeline=True, gnn_graph=True)
+        with torch.no_grad():
+            for s in range(6):
+                piped.step(synth.make_clouds_device(96, 3000, "cuda", seed=s))
+            piped.synchronize()
+        torch.cuda.synchronize()
+        assert n_train == 2 and len(made) > n_train, (n_train, len(made))
+        for cg in made:
+            types = node_types(cg)
+            assert set(types) == {"kernel"} and types["kernel"] >= 8, types

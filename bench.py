@@ -521,15 +521,23 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # NSC_BENCH_RCCL_WORLD1=1 (with --gpus 1): ONE rank, but in the N > 1 shape -- an RCCL process group of one rank, and every
+    # collective of the N > 1 step, calibration and line really issued through it (the backend's stream semantics and
+    # its kernels beside the encoder grid, on the one card a gpurun box has).  Never used for reported numbers.
+    rccl1 = world == 1 and os.environ.get("NSC_BENCH_RCCL_WORLD1") == "1"
+    multi = world > 1 or rccl1
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
+        if rccl1:
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        elif rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
     # self-description of the N > 1 line: how many ranks the communicator really joined (an all-reduce of ones), on what
     rccl_ranks, backend = 1, None
-    if world > 1:
+    if multi:
         ones = torch.ones(1, dtype=torch.float32, device=dev)
         dist.all_reduce(ones)
         rccl_ranks, backend = int(round(float(ones.item()))), str(dist.get_backend())
@@ -617,7 +625,8 @@ def main():
                 else (_PartGnn(args.gnn_nodes) if args.gnn_nodes else model))
         p_ = nd.ShardedDescriptorPath(enc, gnn_, n_total, poses, pipeline=pipelined,
                                       encoder_streams=enc_streams,
-                                      gnn_streams=args.gnn_streams, gnn_graph=None if args.gnn_graph < 0 else bool(args.gnn_graph))
+                                      gnn_streams=args.gnn_streams, gnn_graph=None if args.gnn_graph < 0 else bool(args.gnn_graph),
+                                      rehearse_collectives=rccl1)
         if not pipelined:
             p_.encoder = _Enc
         return p_
@@ -637,7 +646,7 @@ def main():
         want = ["pipelined1" if args.enc_streams == 1 else "pipelined2"]
     elif args.calibrate:
         want = ["pipelined2", "pipelined1", "serial"]
-    elif world == 1 and not args.calibrate2:
+    elif not multi and not args.calibrate2:
         want = ["pipelined1" if args.enc_streams == 1 else "pipelined2"]
     elif args.calibrate2:
         want = ["pipelined2", "serial"]
@@ -654,7 +663,7 @@ def main():
     def sync():
         path.synchronize()                                  # both pipeline streams drained into the current one
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -701,7 +710,7 @@ def main():
                     calib_all.setdefault(name, []).append(round((time.perf_counter() - tc) / CALIB_STEPS * 1e3, 4))
             names = list(paths)
             tcal = torch.tensor([calib[n_] for n_ in names], dtype=torch.float64, device=dev)
-            if world > 1:
+            if multi:
                 dist.all_reduce(tcal, op=dist.ReduceOp.MAX)
             calib = {f"{n_}_ms_per_step": float(tcal[i_]) * 1e3 for i_, n_ in enumerate(names)}
             calib["steps_each"] = 2 * CALIB_STEPS
@@ -723,7 +732,7 @@ def main():
         chosen = [n_ for n_, p_ in paths.items() if p_ is path][0]
         for _ in range(args.warmup):                        # the W untimed warmup steps of the contract
             path.step(next_batch(), inputs_ready=True)
-        if world > 1:
+        if multi:
             # HIP events around the descriptor all-gather, on the stream it is issued on (every step's; allocated here,
             # outside the timed region)
             path.collective_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -744,7 +753,7 @@ def main():
         dt = time.perf_counter() - t0
         gc.enable()
         if chosen != "serial":
-            desc_local = desc_all[rank * n_local:(rank + 1) * n_local] if world > 1 else desc_all
+            desc_local = desc_all[rank * n_local:(rank + 1) * n_local] if multi else desc_all
         # outside the timed region: the same kernel alone on the device (no GNN co-running), for reference --
         # (a) one launch at a time on one stream, (b) consecutive launches overlapping on two streams
         for a, b in solo:
@@ -764,11 +773,11 @@ def main():
         torch.cuda.synchronize(dev)
         solo_period_ms = ends[3].elapsed_time(ends[-1]) / (len(ends) - 4)
         extras = {}
-        if rank == 0 and world == 1 and not args.no_extras:
+        if rank == 0 and not multi and not args.no_extras:
             extras = measure_extras(enc, model, dev, n_local, scratch, (pts, off))
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     per_rank_ms, allgather = None, None
-    if world > 1:
+    if multi:
         tl = torch.zeros(world, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(tl, t)
         per_rank_ms = [float(v) / args.steps * 1e3 for v in tl.tolist()]
@@ -834,11 +843,13 @@ def main():
                                                     for k in range(min(args.steps, 64))] if args.ev_every == 1 else None)},
             "rccl_ranks": rccl_ranks, "backend": backend, "ms_per_step_by_rank": per_rank_ms, "allgather": allgather,
             "launched_by": ("bench.py itself (N fresh child processes)" if os.environ.get("NSC_BENCH_SELF_LAUNCHED") == "1"
-                            else "torch.distributed.run / caller" if world > 1 else "single process"),
+                            else "torch.distributed.run / caller" if world > 1 else
+                            "single process (RCCL world-1 rehearsal)" if rccl1 else "single process"),
             "step_path": "serial" if chosen == "serial" else "pipelined",
             "encoder_streams": {"pipelined2": 2, "pipelined1": 1}.get(chosen, 1), "calibration": calib,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else "")
+                    + (" (REHEARSAL: one rank in the N > 1 shape, every collective through a one-rank RCCL group)" if rccl1 else ""),
             "config": {
                 "workload": f"{n_local} clouds x {N_POINTS} points per GPU, i.i.d. uniform points in random order "
                             f"(BASELINE.json configs[1]; sensor-ordered clouds: roofline.standalone_launch_ms_by_input_order) "
@@ -891,7 +902,7 @@ def main():
                 "ok": bool(np.all(np.abs(got - odesc) <= 1e-6 * np.abs(odesc) + 1e-9)),
             }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -29,12 +29,12 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def all_gather_descriptors(local: torch.Tensor, n_total: Optional[int] = None,
-                           group=None) -> torch.Tensor:
+                           group=None, single_rank_too: bool = False) -> torch.Tensor:
     """All-gather (N_r, D) shards laid out by shard_range() into the full (N, D) matrix.
 
     Equal shards use a single all_gather_into_tensor (one RCCL collective, no copies); ragged
     shards are padded to the largest shard and trimmed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank_too):
         return local
     world = dist.get_world_size(group)
     n_local, d = int(local.shape[0]), int(local.shape[1])
@@ -178,7 +178,8 @@ class ShardedDescriptorPath:
 
     def __init__(self, encoder, gnn, n_total: int, poses=None, temporal_neighbors: int = 5,
                  n_layers: int = 3, group=None, overlap: bool = True, pipeline: bool = False,
-                 encoder_streams: int = 2, gnn_streams: int = 1, gnn_graph: Optional[bool] = None):
+                 encoder_streams: int = 2, gnn_streams: int = 1, gnn_graph: Optional[bool] = None,
+                 rehearse_collectives: bool = False):
         self.encoder, self.gnn, self.group = encoder, gnn, group
         self.pipeline = pipeline
         self.encoder_streams = max(1, int(encoder_streams))
@@ -201,15 +202,19 @@ class ShardedDescriptorPath:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.lo, self.hi = shard_range(n_total, self.rank, self.world)
-        if self.world > 1:
+        # rehearse_collectives: a ONE-rank process group still issues every collective of the N > 1 step (RCCL world-1
+        # rehearsal on a one-GPU box: the backend's stream semantics and its kernels beside the encoder grid, bench.py
+        # NSC_BENCH_RCCL_WORLD1=1 / tests); without it one rank skips the exchange
+        self._collect = self.world > 1 or (bool(rehearse_collectives) and dist.is_initialized())
+        if self._collect:
             self.gnn_streams = 1           # one communicator: its collectives stay on one stream, in one order on all ranks
         if self.gnn_graph is None:
-            self.gnn_graph = self.world == 1
+            self.gnn_graph = not self._collect
         self.halo = n_layers * (temporal_neighbors // 2)
         n_local = self.hi - self.lo
         # pipeline mode hides the whole exchange + GNN under the next encoder: ONE all-gather per step then (every
         # RCCL kernel has to find room beside a resident encoder grid), no boundary-row pre-exchange
-        self.overlap = (overlap and not pipeline and self.world > 1 and n_total % self.world == 0
+        self.overlap = (overlap and not pipeline and self._collect and n_total % self.world == 0
                         and n_local >= self.halo)
         self._graph = None
         self._own0 = 0
@@ -373,7 +378,7 @@ class ShardedDescriptorPath:
                 parts.append(edges_all[(self.rank + 1) * 2 * h:(self.rank + 1) * 2 * h + h])
             self._graph.x = torch.cat(parts, 0) if len(parts) > 1 else local
             desc_all = gathered
-        elif self.pipeline and self.world > 1 and self.n_total % self.world == 0:
+        elif self.pipeline and self._collect and self.n_total % self.world == 0:
             # pipeline mode: ONE all-gather straight into this step's slot of the rotating gathered-matrix buffers
             # (valid for _PIPE_BUFFERS - 1 further steps, like the descriptor buffers; no allocation per step)
             slot = self._k % self._PIPE_BUFFERS
@@ -384,7 +389,12 @@ class ShardedDescriptorPath:
             self._gather(desc_all, local.contiguous())
             self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]
         else:
-            desc_all = all_gather_descriptors(local, self.n_total, self.group)    # fresh tensor per step
+            ce = self.collective_events if (local.is_cuda and self._collect) else None
+            if ce:
+                ce[self._k % len(ce)][0].record()
+            desc_all = all_gather_descriptors(local, self.n_total, self.group, self._collect)    # fresh tensor per step
+            if ce:
+                ce[self._k % len(ce)][1].record()
             self._graph.x = desc_all[self._wlo:self._wlo + self._graph.num_nodes]
         emb = self._enhance()
         if work is not None:

@@ -333,3 +333,49 @@ def test_equal_shards_at_the_bench_shape_through_hip_kernels(tmp_path, mode):
             assert np.array_equal(z["emb_kept"].view(np.uint32), ref["emb"][lo:hi].view(np.uint32))
         assert np.array_equal(z["retr_idx"], ref["retr_idx"]) and np.array_equal(z["retr_val"].view(np.uint32),
                                                                                   ref["retr_val"].view(np.uint32))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_multi_rank_step_over_a_one_rank_rccl_group(tmp_path):
+    """The N > 1 step with the backend the real run uses: a ONE-rank RCCL process group on the one card of the box
+    (`rehearse_collectives=True` issues every collective of the multi-rank step).  What gloo cannot show: nccl orders a
+    collective on the stream it is issued on and `wait()` does not block the host.  Every form of the step -- two-phase
+    exchange, one gather, pipelined on two / one encoder streams -- equals the exchange-free path bit for bit
+    (tests/rccl_world1_worker.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "rccl_world1_worker.py"), str(_free_port())], env=env,
+                       capture_output=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0 and b"RCCL_WORLD1_OK" in p.stdout, (p.stdout.decode(errors="replace")[-2000:],
+                                                                  p.stderr.decode(errors="replace")[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_in_the_multi_rank_shape_over_a_one_rank_rccl_group(tmp_path):
+    """bench.py's N > 1 code path -- calibration over three step forms with its all-reduce, barriers, HIP events around every
+    step's all-gather, the all-gather alone, the per-rank table -- with every collective through RCCL (NSC_BENCH_RCCL_WORLD1=1:
+    one rank, nccl backend), and the descriptors that went through the gather checked against the oracle."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NSC_BENCH_RCCL_WORLD1="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    p = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "12", "--warmup", "2", "--clouds", "256"], env=env,
+                       capture_output=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["backend"] == "nccl"
+    assert line["calibration"] is not None and set(k for k in line["calibration"] if k.endswith("_ms_per_step")) == {
+        "pipelined2_ms_per_step", "pipelined1_ms_per_step", "serial_ms_per_step"}
+    assert line["allgather"]["events"] == 12 and line["allgather"]["in_situ_ms"] > 0 and line["allgather"]["alone_ms"] > 0
+    assert len(line["ms_per_step_by_rank"]) == 1
+    assert line["parity"]["ok"] is True
+    assert "RCCL" in line["data"] and "rehearsal" in line["launched_by"]

@@ -190,6 +190,67 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     out[i] = accumulate ? out[i] + s : s;
 }
 
+// The slab sums of ALL weight-gradient products of a backward in ONE launch (round 4): nothing inside the backward reads a weight
+// gradient, so every product keeps its slabs in a region of its own and the sums -- same fixed order, same (out + s) -- run once at
+// the end: five 5 us launches per batch become one.
+struct SlabJob {
+    const float *part;
+    float *out;
+    long long MN;
+    int S, accumulate;
+    unsigned blk0;                                                  // first workgroup of this job
+};
+constexpr int SLAB_JOBS = 8;
+struct SlabBatch {
+    SlabJob j[SLAB_JOBS];
+    int n;
+    unsigned blocks;
+};
+struct SlabDefer {                                                  // host side: the regions handed out so far
+    SlabBatch b;
+    float *base;
+    size_t cap, used;                                               // floats
+};
+
+inline float *slab_defer_take(SlabDefer *d, long long MN, int S)
+{
+    if (!d || !d->base || d->b.n >= SLAB_JOBS) return nullptr;
+    const size_t need = ((size_t)MN * (size_t)S + 63) / 64 * 64;
+    if (d->used + need > d->cap) return nullptr;
+    float *p = d->base + d->used;
+    d->used += need;
+    return p;
+}
+
+inline void slab_defer_push(SlabDefer *d, const float *part, float *out, long long MN, int S, int accumulate)
+{
+    SlabJob &J = d->b.j[d->b.n++];
+    J.part = part; J.out = out; J.MN = MN; J.S = S; J.accumulate = accumulate; J.blk0 = d->b.blocks;
+    d->b.blocks += (unsigned)((MN + 255) / 256);
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabBatch b)
+{
+    int j = 0;
+#pragma unroll
+    for (int t = 1; t < SLAB_JOBS; ++t)
+        if (t < b.n && blockIdx.x >= b.j[t].blk0) j = t;
+    const float *__restrict__ part = b.j[j].part;
+    float *__restrict__ out = b.j[j].out;
+    const long long MN = b.j[j].MN;
+    const int S = b.j[j].S;
+    const long long i = (long long)(blockIdx.x - b.j[j].blk0) * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.0f;
+    for (int z = 0; z < S; ++z) s += part[(long long)z * MN + i];     // fixed order: deterministic
+    out[i] = b.j[j].accumulate ? out[i] + s : s;
+}
+
+inline void slab_defer_flush(hipStream_t st, SlabDefer *d)
+{
+    if (d && d->b.n > 0) hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(d->b.blocks), dim3(256), 0, st, d->b);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Weight gradients  dW[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands k-major (dW = dY^T X: the rows of dY and X are the
 // k index), round 4.  The k-major operands need no transpose when the MFMA operand is read element by element: the tiles go
@@ -323,7 +384,7 @@ __global__ __launch_bounds__(512) void gemm_tn_glds_kernel(const float *__restri
 // dW = A^T B over K slabs on gemm_tn_glds_kernel; false when the operands do not fit it (the caller takes gemm_gen_kernel)
 template <int TM>
 bool launch_tn_glds_cfg(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C,
-                        int accumulate, float *slabs, int max_slabs)
+                        int accumulate, float *slabs, int max_slabs, SlabDefer *defer)
 {
     constexpr unsigned lds = 3 * (64 * 64 * TM + 64 * 64) * 4;     // 96 / 144 KB: above 64 KB a kernel is opted in, per device
     static std::atomic<int> opted[16];
@@ -343,14 +404,17 @@ bool launch_tn_glds_cfg(hipStream_t st, const float *A, int lda, const float *B,
     kslab = (kslab + 63) / 64 * 64;
     splits = (K + kslab - 1) / kslab;                               // no empty slab
     const long long MN = (long long)M * N;
+    float *own = slab_defer_take(defer, MN, splits);                // a region of this product's own: its sums wait for the batched launch
+    float *dst = own ? own : slabs;
     hipLaunchKernelGGL(gemm_tn_glds_kernel<TM>, dim3((N + 63) / 64, (M + 64 * TM - 1) / (64 * TM), splits), dim3(512), lds, st, A, lda, B,
-                       ldb, M, N, K, kslab, slabs, MN);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
+                       ldb, M, N, K, kslab, dst, MN);
+    if (own) slab_defer_push(defer, own, C, MN, splits, accumulate);
+    else hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
     return true;
 }
 
 bool launch_tn_glds(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C,
-                    int accumulate, float *slabs, int max_slabs)
+                    int accumulate, float *slabs, int max_slabs, SlabDefer *defer = nullptr)
 {
     if ((lda & 3) || (ldb & 3) || M < 4 || N < 4 || (M & 3) || (N & 3) || K < 1 || !slabs ||
         (reinterpret_cast<unsigned long long>(A) & 15) || (reinterpret_cast<unsigned long long>(B) & 15))
@@ -358,9 +422,9 @@ bool launch_tn_glds(hipStream_t st, const float *A, int lda, const float *B, int
     // the wide products (800 x 256 / 256 x 800: 52 tiles of 64 x 64 x 4 slabs would leave 48 CUs idle) take 128 x 64 tiles:
     // 28 / 26 tiles x 9 slabs = one round of 252 / 234 workgroups
     if (((M + 63) / 64) * ((N + 63) / 64) >= 40 && M >= 128 &&
-        launch_tn_glds_cfg<2>(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, max_slabs))
+        launch_tn_glds_cfg<2>(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, max_slabs, defer))
         return true;
-    return launch_tn_glds_cfg<1>(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, max_slabs);
+    return launch_tn_glds_cfg<1>(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, max_slabs, defer);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1271,7 +1335,7 @@ struct TrainWs {
     // saved by the forward
     size_t z0, mean0, invstd0, h, g, a_src, a_dst, alpha, y, mean, invstd, vvec;
     // backward scratch
-    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, colpart, colpart2, total;
+    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, slab_cap, colpart, colpart2, total;
     size_t nh, nn, hh, nz;
 };
 
@@ -1306,7 +1370,12 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     w.dvvec = o; o += 256;
     size_t big = (size_t)std::max(m->in_dim, m->out_dim) * H;
     if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
-    w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);
+    w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);            // region 0: a product that sums its slabs at once, transposed weights
+    // ... and a region per weight-gradient product of a backward whose sums wait for the batched launch (slab_reduce_multi_kernel)
+    size_t all_w = (size_t)m->in_dim * H + (size_t)m->out_dim * H + (size_t)L * H * H;
+    if (m->residual && m->in_dim != m->out_dim) all_w += (size_t)m->in_dim * m->out_dim;
+    w.slab_cap = all_w * SPLITK_SLABS + 64 * SLAB_JOBS;            // floats
+    o += align256(w.slab_cap * 4);
     w.colpart = o; o += align256((size_t)COLRED_MAXR * std::max(std::max(H, m->out_dim), m->in_dim) * 2 * 8);
     w.colpart2 = o; o += align256((size_t)COLRED_MAXR * H * 8);      // partials of the bias gradient (bn_apply_colsum_kernel)
     w.total = o;
@@ -1336,7 +1405,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // buffer, free between two weight-gradient products of the stream, takes the transposed weight.
 template <bool AKM, bool BKM>
 void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
-          const float *bias, int accumulate, int splits, float *slabs)
+          const float *bias, int accumulate, int splits, float *slabs, SlabDefer *defer = nullptr)
 {
     if (!AKM && splits <= 1 && (!BKM || (slabs && !(K & 15) && !(reinterpret_cast<unsigned long long>(slabs) & 15)))) {
         // the projections of the training forward, and the dX = dY W products of the backward through a transposed copy of
@@ -1362,7 +1431,7 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
         if (accumulate) { ep.resid = C; ep.ldr = ldc; }
         if (launch_glds<2>(st, A, lda, Bn, ldn, nullptr, M, N, N, K, C, ldc, ep)) return;
     }
-    if (AKM && BKM && splits > 1 && !bias && ldc == N && launch_tn_glds(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, SPLITK_SLABS))
+    if (AKM && BKM && splits > 1 && !bias && ldc == N && launch_tn_glds(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, SPLITK_SLABS, defer))
         return;
     dim3 grid((N + 63) / 64, (M + 31) / 32, splits);
     if (splits <= 1) {
@@ -1371,10 +1440,12 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
     } else {
         int kchunk = (K + splits - 1) / splits;
         kchunk = (kchunk + 63) / 64 * 64;
-        hipLaunchKernelGGL((gemm_gen_kernel<AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, K, kchunk, slabs,
-                           N, (long long)M * N, static_cast<const float *>(nullptr), 0);
         const long long MN = (long long)M * N;      // requires ldc == N
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
+        float *own = slab_defer_take(defer, MN, splits);
+        hipLaunchKernelGGL((gemm_gen_kernel<AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, K, kchunk, own ? own : slabs,
+                           N, MN, static_cast<const float *>(nullptr), 0);
+        if (own) slab_defer_push(defer, own, C, MN, splits, accumulate);
+        else hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
     }
 }
 
@@ -1572,12 +1643,21 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     if (N == 0) return NSC_OK;
     const TrainWs w = train_ws(m, N, g->nnz);
     if (!ws || ws_bytes < w.total) return NSC_EWORKSPACE;
+    if (m->residual && Din != Dout && (!gr->res_w || !gr->res_b)) return NSC_EINVAL;   // (before anything is enqueued)
     hipStream_t st = static_cast<hipStream_t>(stream_);
     char *b = static_cast<char *>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
     double *colpart2 = reinterpret_cast<double *>(b + w.colpart2);
     float *slabs = F(w.slabs);
+    SlabDefer defer_ = {};
+    {
+        size_t big = (size_t)std::max(Din, Dout) * H;
+        if (m->residual && Din != Dout) big = std::max(big, (size_t)Din * Dout);
+        defer_.base = slabs + align256(big * 4 * SPLITK_SLABS) / 4;
+        defer_.cap = w.slab_cap;
+    }
+    SlabDefer *defer = &defer_;
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
     const int splits = N >= 512 ? SPLITK_SLABS : 1;
@@ -1587,14 +1667,13 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
 
     // output_proj: out = h_L W_out^T + b (+ x)
     colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr, acc);
-    gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, acc, splits, slabs);
+    gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, acc, splits, slabs, defer);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
     gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, slabs);   // dh_L = dOut W_out
     const bool res_id = m->residual && Din == Dout, res_proj = m->residual && Din != Dout;
     if (res_proj) {                // residual_proj: dW_res = dOut^T x, db_res = colsum dOut      model.py:147-149
-        if (!gr->res_w || !gr->res_b) return NSC_EINVAL;
         colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->res_b, nullptr, nullptr, nullptr, acc);
-        gemm<true, true>(st, grad_out, Dout, x, Din, Dout, Din, N, gr->res_w, Din, nullptr, acc, splits, slabs);
+        gemm<true, true>(st, grad_out, Dout, x, Din, Dout, Din, N, gr->res_w, Din, nullptr, acc, splits, slabs, defer);
     }
     if (gr->x) {
         // gradient wrt the input features through the residual connection: dOut itself (identity residual),
@@ -1666,7 +1745,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
             }
         }
         // g = h_l W^T :  dW = dG^T h_l ,  dh_l = dG W (+ residual path)
-        gemm<true, true>(st, dG, H, hin, H, H, H, N, Gl.lin_w, H, nullptr, acc, splits, slabs);
+        gemm<true, true>(st, dG, H, hin, H, H, H, N, Gl.lin_w, H, nullptr, acc, splits, slabs, defer);
         gemm<false, true>(st, dG, H, Ly.lin_w, H, N, H, H, dh_prev, H, nullptr, 0, 1, slabs);
         if (has_res) hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh_prev, dh, NH);
         float *t = dh; dh = dh_prev; dh_prev = t;
@@ -1675,10 +1754,11 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     float *dv = F(w.dv), *s1 = F(w.s1), *s2 = F(w.s2);
     bias_final(st, H, bn_backward(st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u,
                                   N, H, dv, s1, s2, gr->in_bn_b, gr->in_bn_w, acc, colpart, colpart2, gr->in_b));
-    gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, acc, splits, slabs);
+    gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, acc, splits, slabs, defer);
     if (gr->x) {   // + dZ0 W_in
         gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, slabs);
     }
+    slab_defer_flush(st, defer);                                    // every weight gradient's slab sum, one launch
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

@@ -124,10 +124,33 @@ def _train_forward_raw(gnn, x, csr, dropout_p, seed):
         st = L.nsc_gat_forward_train(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
                                      C.byref(cfg), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
     _lib.check(st, "nsc_gat_forward_train")
-    for bn in [gnn.input_norm] + list(gnn.batch_norms):
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+    _bump_batches_tracked(gnn)
     return out, (csr, cfg, ws, nbytes, x, sd)
+
+
+def _bump_batches_tracked(gnn):
+    """``num_batches_tracked += 1`` of every BatchNorm (what torch's own train-mode forward does) as ONE launch: the counters
+    are 0-d views of one int64 vector (set up outside a capture, re-made whenever a ``.to()`` / a new buffer broke the aliasing;
+    ``load_state_dict`` copies in place and keeps it).  Four 4 us kernels per batch of the captured training step were these."""
+    bns = [bn for bn in [gnn.input_norm] + list(gnn.batch_norms) if bn.num_batches_tracked is not None]
+    if not bns:
+        return
+    bufs = [bn.num_batches_tracked for bn in bns]
+    flat = gnn.__dict__.get("_nbt_flat")
+    ok = (flat is not None and flat.numel() == len(bufs) and flat.device == bufs[0].device
+          and all(b_.dtype == flat.dtype and b_.dim() == 0 and b_.device == flat.device
+                  and b_.data_ptr() == flat.data_ptr() + i * flat.element_size() for i, b_ in enumerate(bufs)))
+    if not ok:
+        same = all(b_.dim() == 0 and b_.dtype == bufs[0].dtype and b_.device == bufs[0].device for b_ in bufs)
+        if not same or (bufs[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+            for b_ in bufs:                                  # unusual buffers, or no allocation wanted inside a capture
+                b_ += 1
+            return
+        flat = torch.stack([b_.detach() for b_ in bufs])
+        for i, bn in enumerate(bns):
+            bn._buffers["num_batches_tracked"] = flat[i]
+        gnn.__dict__["_nbt_flat"] = flat
+    flat += 1
 
 
 def _train_backward_raw(gnn, state, grad_out, grads, accumulate, need_x):
@@ -232,6 +255,7 @@ class SpectralGNN(nn.Module):
         state["_seed_dev"] = None
         state["_fold_generation"] = 0
         state.pop("_live_slots", None)
+        state.pop("_nbt_flat", None)
         state["_direct_grads"] = False
         return state
 

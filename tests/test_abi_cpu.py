@@ -316,3 +316,43 @@ def test_no_memset_or_memcpy_nodes_on_capturable_paths():
     for f in src:
         code = re.sub(r"//[^\n]*", "", open(f).read())
         assert "hipMemsetAsync" not in code and "hipMemcpyAsync" not in code and "hipMemset(" not in code, f
+
+
+def test_batchnorm_step_counters_are_one_vector():
+    """gnn/model.py::_bump_batches_tracked: the four ``num_batches_tracked`` counters count like torch's own train-mode
+    forward would, as 0-d views of one vector (one launch per training forward instead of four); state_dict keys and values,
+    load_state_dict, deepcopy, dtype casts and torch.save keep working."""
+    import copy
+    import io
+    import torch
+    from neural_spectral_codec_amd.gnn.model import create_spectral_gnn, _bump_batches_tracked
+    m = create_spectral_gnn(edge_dim=2)
+    g = m.gnn
+    bns = [g.input_norm] + list(g.batch_norms)
+    bns[1].num_batches_tracked.fill_(7)
+    _bump_batches_tracked(g)
+    _bump_batches_tracked(g)
+    assert [int(b.num_batches_tracked) for b in bns] == [2, 9, 2, 2]
+    flat = g._nbt_flat
+    assert all(b.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, b in enumerate(bns))
+    sd = copy.deepcopy(m.state_dict())
+    assert sorted(k for k in sd if "num_batches" in k) == sorted(
+        ["gnn.input_norm.num_batches_tracked"] + [f"gnn.batch_norms.{i}.num_batches_tracked" for i in range(3)])
+    _bump_batches_tracked(g)
+    m.load_state_dict(sd)                                   # copies in place: the views stay views
+    assert g._nbt_flat is flat and flat.tolist() == [2, 9, 2, 2]
+    m2 = copy.deepcopy(m)
+    _bump_batches_tracked(m2.gnn)
+    assert [int(b.num_batches_tracked) for b in [m2.gnn.input_norm] + list(m2.gnn.batch_norms)] == [3, 10, 3, 3]
+    assert flat.tolist() == [2, 9, 2, 2]                    # the copy counts on its own
+    m.double()                                              # module._apply: buffers may be re-made
+    _bump_batches_tracked(g)
+    assert [int(b.num_batches_tracked) for b in bns] == [3, 10, 3, 3]
+    f = io.BytesIO()
+    torch.save(m.state_dict(), f)
+    f.seek(0)
+    back = torch.load(f)
+    assert int(back["gnn.batch_norms.0.num_batches_tracked"]) == 10 and int(back["gnn.input_norm.num_batches_tracked"]) == 3
+    bns[2].num_batches_tracked = None                       # a BatchNorm without the counter (track_running_stats off)
+    _bump_batches_tracked(g)
+    assert [int(b.num_batches_tracked) for b in bns if b.num_batches_tracked is not None] == [4, 11, 4]

@@ -371,3 +371,25 @@ def test_intensity_image_matches_reference():
     from neural_spectral_codec_amd.encoding.range_image import project_to_range_image
     r4 = project_to_range_image(g["c0_pts"], n_elevation=16)
     assert (r4.view(np.uint32) == g["c0_range"].view(np.uint32)).all()
+
+
+def test_batch_whose_offsets_pass_2_31_floats():
+    """Maximum sizes: 4 600 clouds x 120 000 points in ONE call = 2.2e9 floats (8.8 GB): the float offset of the last clouds'
+    points lies beyond 2^31 and their byte offset beyond 2^33 -- every cloud's base is 64-bit arithmetic on cloud_offsets
+    (int64), only the offsets INSIDE a cloud are 32-bit.  The last clouds' descriptors and range images equal what the same
+    clouds give as a small batch of their own, bit for bit, and the oracle's on a sample."""
+    enc = _enc()
+    n, npts = 4600, 120000
+    pts, off = synth.make_clouds_device(n, npts, "cuda", seed=11)
+    assert pts.numel() > 2 ** 31 and int(off[-1]) == n * npts
+    d, raw, _ = enc.encode_points_batch((pts, off), return_images=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(d.sum(1), torch.ones(n, device="cuda"), atol=1e-5)
+    for lo, hi in ((0, 4), (4470, 4482), (n - 12, n)):         # first clouds, the ones around 2^31 floats, the last ones
+        sub = pts[lo * npts:hi * npts].clone()
+        soff = torch.arange(0, (hi - lo + 1) * npts, npts, dtype=torch.int64, device="cuda")
+        ds, rs, _ = enc.encode_points_batch((sub, soff), return_images=True)
+        assert torch.equal(ds, d[lo:hi]) and torch.equal(rs, raw[lo:hi]), (lo, hi)
+    for c in (4474, n - 1):
+        host = pts[c * npts:(c + 1) * npts].cpu().numpy()
+        assert _close(d[c].cpu().numpy(), orc.encode_points(host), 1e-6, 1e-9)

@@ -411,3 +411,36 @@ def test_scratch_cache_is_bounded_and_never_replaces_a_buffer():
         assert c.get("cuda:0", 512, "captured") is pinned
     c.release()
     assert len(c) == 0
+
+
+def test_graph_whose_feature_matrix_passes_2_31_elements():
+    """Maximum sizes: a 2.75 M-keyframe temporal chain -- x and the output hold 2.2e9 floats each (8.8 GB), so the element offset
+    of the last 65 000 rows lies beyond 2^31.  Windows at the start, across row 2^31 / 800 and at the end are checked against
+    the restatement evaluated on the window + a 6-node halo (3 layers x 2 hops: the interior rows are exact), and the generic
+    kernel set must give the same bits as the one-launch banded layers everywhere."""
+    n = 2_750_000
+    m = _model()
+    feats = torch.rand((n, 800), device="cuda")
+    feats.pow_(4)
+    feats.div_(feats.sum(1, keepdim=True))
+    from neural_spectral_codec_amd import synth
+    g = gm.build_chain_graph(feats, 5, "cuda", synth.make_pose_chain(n, 0))
+    assert g.x.numel() > 2 ** 31 and g.x.data_ptr() == feats.data_ptr()
+    with torch.no_grad():
+        out = m(g)
+        assert m.gnn._csr(g, True).band == 2
+        m.gnn.coresident = "generic"
+        gen = m(g)
+        m.gnn.coresident = False
+    torch.cuda.synchronize()
+    assert out.shape == (n, 800) and torch.equal(out, gen)
+    del gen
+    cut = 2 ** 31 // 800
+    for a, b in ((0, 150), (cut - 60, cut + 60), (n - 150, n)):
+        wlo, whi = max(0, a - 6), min(n, b + 6)
+        ei = g.edge_index
+        keep = (ei[0] >= wlo) & (ei[0] < whi) & (ei[1] >= wlo) & (ei[1] < whi)
+        sub = gm.Data(x=g.x[wlo:whi].cpu(), edge_index=(ei[:, keep] - wlo).cpu(), edge_attr=g.edge_attr[keep].cpu(),
+                      num_nodes=whi - wlo)
+        ref = go.forward_reference(m, sub, dtype=torch.float64)
+        go.assert_within_bar(out[a:b], ref[a - wlo:b - wlo], what=f"rows {a}..{b} vs float64 restatement")

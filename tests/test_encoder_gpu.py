@@ -393,3 +393,44 @@ def test_batch_whose_offsets_pass_2_31_floats():
     for c in (4474, n - 1):
         host = pts[c * npts:(c + 1) * npts].cpu().numpy()
         assert _close(d[c].cpu().numpy(), orc.encode_points(host), 1e-6, 1e-9)
+
+
+@pytest.mark.parametrize("shape", ["fast", "fused", "split", "range_images"])
+def test_encoder_entry_points_replay_as_a_captured_graph(shape):
+    """include/nsc.h: every call is asynchronous, allocates nothing, keeps no state and may be captured into a hipGraph.  Each
+    path of nsc_encode_clouds (the streaming fast kernel, the fused kernel of other shapes, the split path with its workspace
+    fill -- a kernel, not a memset node) and nsc_encode_range_images is captured once and replayed on NEW input written into
+    the same buffers: the replay gives what an eager call on that input gives, bit for bit."""
+    from neural_spectral_codec_amd import _lib
+    L = _lib.lib()
+    if shape == "range_images":
+        enc = _enc()
+        a, b = (torch.rand((32, 16, 360), device="cuda", generator=torch.Generator("cuda").manual_seed(s)) * 60 for s in (1, 2))
+        run = lambda x: enc(x)
+        inputs = (a, b)
+    else:
+        enc = _enc(E={"fast": 16, "fused": 64, "split": 16}[shape])
+        n, npts = {"fast": (64, 30000), "fused": (64, 30000), "split": (2, 400000)}[shape]
+        batches = [synth.make_clouds_device(n, npts, "cuda", seed=s) for s in (5, 6)]
+        assert L.nsc_encode_clouds_path(n, n * npts, 4, enc._params()) == {"fast": 1, "fused": 2, "split": 3}[shape]   # NSC_ENC_PATH_*
+        off = batches[0][1]
+        run = lambda x: enc.encode_points_batch((x, off))
+        inputs = (batches[0][0], batches[1][0])
+    with torch.no_grad():
+        want = [run(x).clone() for x in inputs]
+        buf = inputs[0].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run(buf)                                           # warm-up on the capturing stream (lazy set-up, scratch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            out = run(buf)
+        for x, w in zip((inputs[1], inputs[0], inputs[1]), (want[1], want[0], want[1])):
+            buf.copy_(x)
+            cg.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, w)
+    assert not torch.equal(want[0], want[1])

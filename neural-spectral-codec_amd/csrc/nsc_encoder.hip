@@ -47,15 +47,16 @@ struct EncDev {
     int interp;
 #ifdef NSC_DEV_TUNING
     int dev_skip;          // development builds only (NSC_TUNE_SKIP_FINISH): phase masks for tools/ab_enc.py
-    int dev_stagger;       // development: start delay per CU slot, in units of 64 clocks (NSC_TUNE_STAGGER)
 #endif
 };
 
 // Phase masks exist only in development builds (NSC_DEV_BUILD=1); the shipped kernels carry none of it.
 #ifdef NSC_DEV_TUNING
 #define NSC_DEV_SKIP(d, bit) (((d).dev_skip & (bit)) != 0)
+#define NSC_DEV_MODE(d) ((d).dev_skip)
 #else
 #define NSC_DEV_SKIP(d, bit) false
+#define NSC_DEV_MODE(d) 0
 #endif
 
 // exp(-2 pi i j / 360) = (cos, -sin): table holds (cos, sin)
@@ -702,7 +703,7 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
 // "+v" operand of BOTH statements, so the compiler holds it in one register quad and never reads it between the load
 // and the wait; every statement is volatile with a memory clobber (program order is kept); the last round issues no
 // loads and counts its waits down to vmcnt(0), so nothing is in flight when the registers are reused.
-template <int NT, int U, bool PAIR = true>
+template <int NT, int U>
 __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, int tid, const NscBinParams &bp,
                                             unsigned *img, f32x4 *queue, unsigned *qcount, int dev_mode = 0)
 {
@@ -765,24 +766,13 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
     });
     constexpr unsigned RB = (unsigned)(U * NT * 16);                 // bytes per round
     static_assert(U % 2 == 0, "slots are binned in pairs");
-#ifdef NSC_DEV_TUNING
-    // development A/B (NSC_TUNE_VARIANT=-4): one point at a time through the scalar nsc_point_lean_flags
-    auto process1 = [&](const f32x4 &v) {
-        int pix; float s; bool certain;
-        if (!nsc_point_lean_flags(v.x, v.y, v.z, bp, pix, s, certain)) return;
-        if (certain) atomicMin(&img[pix], __float_as_uint(s)); else park(v, s);
-    };
-#define NSC_PROCESS2(a, b) do { if constexpr (PAIR) process2(a, b); else { process1(a); process1(b); } } while (0)
-#else
-#define NSC_PROCESS2(a, b) process2(a, b)
-#endif
     for (int r = 0; r + 2 < T; ++r) {            // rounds whose refill (round r + 1) is complete: no clamping
         static_for<U / 2>([&](auto uc) {
             constexpr int u = 2 * decltype(uc)::value;
             f32x4 &slot = buf[u], &slot1 = buf[u + 1];
             const unsigned long long base_ = Pb;
             NSC_SLOT_WAIT2(slot, slot1, U - 2);
-            NSC_PROCESS2(slot, slot1);
+            process2(slot, slot1);
             const unsigned a = o + RB + (unsigned)(u * NT * 16), a1 = a + (unsigned)(NT * 16);
             NSC_SLOT_LOAD(slot, a);
             NSC_SLOT_LOAD(slot1, a1);
@@ -792,9 +782,6 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
         // stay in flight across it).  Waves that drift apart turn the workgroup's 32 KB-per-round sequential sweep into
         // four unrelated streams; in step, the same kernel measured 2.2-2.7 % faster (interleaved A/B, round 2) and the
         // four waves also reach the finish together.  Every wave runs the same number of rounds (T depends on n only).
-#ifdef NSC_DEV_TUNING
-        if (!(dev_mode & 256))
-#endif
         __builtin_amdgcn_s_barrier();
     }
     if (T >= 2) {                                // round T - 2: its refill is the last, possibly partial, round
@@ -803,7 +790,7 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
             f32x4 &slot = buf[u], &slot1 = buf[u + 1];
             const unsigned long long base_ = Pb;
             NSC_SLOT_WAIT2(slot, slot1, U - 2);
-            NSC_PROCESS2(slot, slot1);
+            process2(slot, slot1);
             const unsigned a = min(o + RB + (unsigned)(u * NT * 16), last);
             const unsigned a1 = min(o + RB + (unsigned)((u + 1) * NT * 16), last);
             NSC_SLOT_LOAD(slot, a);
@@ -818,9 +805,8 @@ __device__ __forceinline__ void stream_fast(const f32x4 *__restrict__ P, int n, 
         f32x4 v = slot, v1 = slot1;
         if (o + (unsigned)(u * NT * 16) > last) v.x = NAN;          // past the cloud: fails the range window
         if (o + (unsigned)((u + 1) * NT * 16) > last) v1.x = NAN;
-        NSC_PROCESS2(v, v1);
+        process2(v, v1);
     });
-#undef NSC_PROCESS2
 #undef NSC_SLOT_WAIT2
 #undef NSC_SLOT_LOAD
 #ifdef NSC_DEV_TUNING
@@ -1037,25 +1023,14 @@ __device__ __forceinline__ void finish_fast(unsigned char *lds, const EncDev &d,
 #undef NSC_STAMP
 }
 
-template <int U, bool PAIR = true>
+template <int U>
 __global__ __launch_bounds__(256, 6) void encode_fast_kernel(
     const float *__restrict__ pts, const long long *__restrict__ off, EncDev d, const int *__restrict__ lut,
     float *__restrict__ out_desc, float *__restrict__ out_raw, float *__restrict__ out_interp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int NT = 256;
-#ifdef NSC_ENC_XCD_REMAP
-    // A/B build (round 4): workgroups are dealt round-robin over the 8 XCDs; give every XCD a CONTIGUOUS range of clouds
-    // instead of every eighth one (measured: no difference -- the odd XCDs finish ~12 us after the even ones either way)
-    int c;
-    {
-        const unsigned id = blockIdx.x, n_ = gridDim.x, xcd = id & 7u, q_ = n_ >> 3, r_ = n_ & 7u;
-        c = (int)((xcd < r_ ? xcd * (q_ + 1u) : r_ * (q_ + 1u) + (xcd - r_) * q_) + (id >> 3));
-    }
-    const int tid = threadIdx.x;
-#else
     const int c = blockIdx.x, tid = threadIdx.x;
-#endif
     const FastLds lp = fast_lds(d.B);
     unsigned *img = reinterpret_cast<unsigned *>(lds + lp.img);
     f32x4 *queue = reinterpret_cast<f32x4 *>(lds + lp.aux);
@@ -1077,18 +1052,8 @@ __global__ __launch_bounds__(256, 6) void encode_fast_kernel(
 #ifdef NSC_DEV_TUNING
     const unsigned long long dev_t0 = wall_clock64();
     unsigned long long dev_t1 = 0;
-    if (NSC_DEV_SKIP(d, 32)) __builtin_amdgcn_s_setprio(3);
-    if (d.dev_stagger > 0) {          // workgroups b, b + 256, b + 512, b + 768 are expected to share a CU
-        const int units = ((blockIdx.x >> 8) & 3) * d.dev_stagger;
-        for (int u = 0; u < units; u += 100) __builtin_amdgcn_s_sleep(100);
-    }
 #endif
-    if (n > 0 && !NSC_DEV_SKIP(d, 2))
-#ifdef NSC_DEV_TUNING
-        stream_fast<NT, U, PAIR>(P, n, tid, d.bp, img, queue, qcount, d.dev_skip);
-#else
-        stream_fast<NT, U, PAIR>(P, n, tid, d.bp, img, queue, qcount);
-#endif
+    if (n > 0 && !NSC_DEV_SKIP(d, 2)) stream_fast<NT, U>(P, n, tid, d.bp, img, queue, qcount, NSC_DEV_MODE(d));
     __syncthreads();
     {   // drain the uncertain-point queue with the exact chain (the definition of the pixel), compacted
         const unsigned qn = *qcount;
@@ -1300,7 +1265,6 @@ EncDev make_dev(const NscEncParams *p, int rows_in)
     d.interp = p->interpolate;
 #ifdef NSC_DEV_TUNING
     d.dev_skip = tune_env("NSC_TUNE_SKIP_FINISH", 0);
-    d.dev_stagger = tune_env("NSC_TUNE_STAGGER", 0);
 #endif
     return d;
 }
@@ -1413,27 +1377,6 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
     if (path != NSC_ENC_PATH_SPLIT) {
         if (path == NSC_ENC_PATH_FAST) {
             const FastLds fl = fast_lds(d.B);
-#ifdef NSC_DEV_TUNING
-            if (variant == -1)
-                hipLaunchKernelGGL(encode_fast_kernel<4>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
-                                   out_desc, out_raw, out_interp);
-            else if (variant == -2)
-                hipLaunchKernelGGL(encode_fast_kernel<16>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
-                                   out_desc, out_raw, out_interp);
-            else if (variant == -3)
-                hipLaunchKernelGGL(encode_fast_kernel<12>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
-                                   out_desc, out_raw, out_interp);
-            else if (variant == -5)
-                hipLaunchKernelGGL(encode_fast_kernel<8>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
-                                   out_desc, out_raw, out_interp);
-            else if (variant == -6)
-                hipLaunchKernelGGL(encode_fast_kernel<6>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
-                                   out_desc, out_raw, out_interp);
-            else if (variant == -4)
-                hipLaunchKernelGGL((encode_fast_kernel<8, false>), dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d,
-                                   lut, out_desc, out_raw, out_interp);
-            else
-#endif
                 // two loads per lane: measured against 4, 6, 8 and 12, alone 1-2 % faster on uniform and 3-4 % on
                 // ring-ordered clouds, identical in the two-stream step (round 2, interleaved A/B)
                 hipLaunchKernelGGL(encode_fast_kernel<2>, dim3(n_clouds), dim3(256), fl.total, stream, pts, off, d, lut,
@@ -1450,20 +1393,14 @@ int nsc_encode_clouds(const float *pts, const int64_t *cloud_offsets, int32_t n_
     }
         // 16 waves per CU in every shape: the LDS image decides how many workgroups share a CU, the workgroup
         // brings the waves (E <= 16: 4 x 4 waves, <= 32 rows: 2 x 8, up to 64 rows: 1 x 16)
-        if (d.E > 32) {
-            if (variant == 1) NSC_LAUNCH_FUSED(16, 8, 1) else NSC_LAUNCH_FUSED(16, 4, 1)
-        } else if (d.E > 16) {
-            if (variant == 1) NSC_LAUNCH_FUSED(8, 8, 2) else NSC_LAUNCH_FUSED(8, 4, 2)
-        } else switch (variant) {
-        case 1: NSC_LAUNCH_FUSED(4, 8, 4) break;
-        case 3: NSC_LAUNCH_FUSED(8, 4, 4) break;
-        case 4: NSC_LAUNCH_FUSED(8, 8, 2) break;
-        case 5: NSC_LAUNCH_FUSED(16, 8, 1) break;
-        // default: 4 waves x 4 float4 loads in flight per lane (92 VGPRs), 39.4 KB LDS -> 4 workgroups per CU:
-        // a 1 024-cloud batch is exactly one resident round.  Interleaved A/B on three boxes: 1-1.5 % faster than 8
-        // loads per lane (108 VGPRs), and it leaves 128 VGPRs per SIMD lane to co-resident kernels.
-        default: NSC_LAUNCH_FUSED(4, 4, 4) break;
-        }
+        // (the wave / load-depth shapes measured against these in rounds 1-2 -- 8 loads per lane, 8 or 16 waves on 16 rows --
+        // are DESIGN.md section 7, experiments 1-12; the library instantiates only what it launches)
+        if (d.E > 32) NSC_LAUNCH_FUSED(16, 4, 1)
+        else if (d.E > 16) NSC_LAUNCH_FUSED(8, 4, 2)
+        // 4 waves x 4 float4 loads in flight per lane (92 VGPRs), 39.4 KB LDS -> 4 workgroups per CU: a 1 024-cloud batch is
+        // exactly one resident round.  Interleaved A/B on three boxes: 1-1.5 % faster than 8 loads per lane (108 VGPRs), and
+        // it leaves 128 VGPRs per SIMD lane to co-resident kernels.
+        else NSC_LAUNCH_FUSED(4, 4, 4)
     } else {
         const size_t need = (size_t)n_clouds * d.E * A * sizeof(unsigned);
         if (!ws || ws_bytes < need) return NSC_EWORKSPACE;

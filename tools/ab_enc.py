@@ -1,5 +1,6 @@
 """Interleaved A/B timing of encoder variants (median of rounds) -- robust against box-to-box and
-minute-to-minute clock drift.  usage: ab_enc.py "VARIANT=0" "VARIANT=1,STAGGER_US=4" ..."""
+minute-to-minute clock drift.  usage: ab_enc.py "VARIANT=0" "VARIANT=1" "VARIANT=0,SKIP_FINISH=64" ...
+(VARIANT 0 = encode_fast_kernel, 1 = the fused kernel forced; SKIP_FINISH = phase masks of csrc/nsc_encoder.hip)"""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -517,11 +517,11 @@ __device__ __forceinline__ void colreduce_local(const double *__restrict__ part,
 // ticket, finishing the sum: the release / acquire fences it needs are an L2 write-back + invalidate on an 8-XCD part, and the
 // fused kernel took 26.5 us where the two launches take 8 + 5.5 -- the whole training step got slower by a third of its kernel
 // time.  Two launches it stays; inside a captured hipGraph the second launch costs about a microsecond.)
-__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__restrict__ P, const float *__restrict__ w,
-                                                                const float *__restrict__ Q, const float *__restrict__ qm,
-                                                                const float *__restrict__ qs, int N, int C,
-                                                                int rows_per_block, double *__restrict__ part,
-                                                                const float *__restrict__ w2)
+__device__ __forceinline__ void colreduce_partial_body(const float *__restrict__ P, const float *__restrict__ w,
+                                                       const float *__restrict__ Q, const float *__restrict__ qm,
+                                                       const float *__restrict__ qs, int N, int C,
+                                                       int rows_per_block, double *__restrict__ part,
+                                                       const float *__restrict__ w2)
 {
     // w2 (with Q null): out_b[c] = sum_n P[n][c] * w2[n] -- the two attention-vector gradients of a layer read the same
     // matrix with two weight vectors: one pass instead of two
@@ -567,6 +567,28 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__r
     }
 }
 
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__restrict__ P, const float *__restrict__ w,
+                                                                const float *__restrict__ Q, const float *__restrict__ qm,
+                                                                const float *__restrict__ qs, int N, int C,
+                                                                int rows_per_block, double *__restrict__ part,
+                                                                const float *__restrict__ w2)
+{
+    colreduce_partial_body(P, w, Q, qm, qs, N, C, rows_per_block, part, w2);
+}
+
+// The attention-vector gradients of ALL layers (datt_src = sum_j da_src[j] g_j, datt_dst likewise: two weighted column sums of
+// the layer's saved G) in one launch at the end of the backward, blockIdx.z = layer (round 4: nothing inside the backward reads
+// them; every layer keeps its da_src / da_dst and its partials in buffers of its own).
+struct ColPartJobs {
+    const float *P[NSC_GAT_MAX_LAYERS], *w[NSC_GAT_MAX_LAYERS], *w2[NSC_GAT_MAX_LAYERS];
+    double *part[NSC_GAT_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void colreduce_partial_layers_kernel(ColPartJobs j, int N, int C, int rows_per_block)
+{
+    const int l = blockIdx.z;
+    colreduce_partial_body(j.P[l], j.w[l], nullptr, nullptr, nullptr, N, C, rows_per_block, j.part[l], j.w2[l]);
+}
+
 // A second, one-component sum that rides along a final pass (round 4): out[c] (+)= sum_r part[r][c], float64 partials of
 // ANOTHER matrix written by an earlier kernel of the stream (the conv / input bias gradient, whose pass 1 is fused into
 // bn_apply_colsum_kernel: one launch and one read of the (N, H) matrix less per BatchNorm).
@@ -577,8 +599,8 @@ struct ColExtra {
 };
 
 // Pass 2: the R partial rows of a 64-column block, summed in fixed order (deterministic), then the finish (ColFinal).
-__global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C, ColFinal f,
-                                                              ColExtra x)
+__device__ __forceinline__ void colreduce_final_body(const double *__restrict__ part, int R, int C, const ColFinal &f,
+                                                     const ColExtra &x)
 {
     __shared__ double sa[256], sb[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -596,6 +618,29 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__re
             x.out[c] = x.acc ? x.out[c] + (float)a : (float)a;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C, ColFinal f,
+                                                              ColExtra x)
+{
+    colreduce_final_body(part, R, C, f, x);
+}
+
+// Every final pass a backward has left for its end, one launch (blockIdx.y = job): the attention-vector gradients of the layers
+// with the conv-bias finals riding along, the output bias, the input bias.
+constexpr int COL_JOBS = NSC_GAT_MAX_LAYERS + 2;
+struct ColFinalJobs {
+    const double *part[COL_JOBS];
+    int R[COL_JOBS], C[COL_JOBS];
+    ColFinal f[COL_JOBS];
+    ColExtra x[COL_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(256) void colreduce_final_jobs_kernel(ColFinalJobs j)
+{
+    const int l = blockIdx.y;
+    if ((int)blockIdx.x * 64 >= j.C[l]) return;                     // (workgroup-uniform: ahead of every barrier)
+    colreduce_final_body(j.part[l], j.R[l], j.C[l], j.f[l], j.x[l]);
 }
 
 // BatchNorm backward, pass 1, with the activation backward fused in (round 4: bn_act_bwd_dv_kernel + colreduce_partial_kernel
@@ -1166,9 +1211,13 @@ __global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restric
                                                             const int *__restrict__ tgt,
                                                             const float *__restrict__ loop_attr,
                                                             const float *__restrict__ edge_attr,
-                                                            const float *__restrict__ draw, int N, int edge_dim,
-                                                            double *__restrict__ part)
+                                                            const float *__restrict__ draw_all, long long draw_stride,
+                                                            int N, int edge_dim, double *__restrict__ part_all)
 {
+    // blockIdx.y = layer (round 4: the edge terms of ALL layers in one launch at the end of the backward; every layer keeps its
+    // d logit / d raw in a buffer of its own)
+    const float *__restrict__ draw = draw_all + (long long)blockIdx.y * draw_stride;
+    double *__restrict__ part = part_all + (long long)blockIdx.y * EDGE_BWD_WGS * NSC_GAT_MAX_EDGE_DIM;
     __shared__ double sh[256];
     const int nnz = row_ptr[N];
     double s[NSC_GAT_MAX_EDGE_DIM];
@@ -1196,11 +1245,18 @@ __global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restric
 // (round 4: one launch instead of edge_term_bwd_final_kernel + edge_vec_bwd_kernel)  dv[d] = sum of the workgroups' partials in a
 // fixed shuffle tree (deterministic), then the backward of v = W_edge^T att_edge: dW_edge[c,d] = dv[d] att_edge[c],
 // datt_edge[c] = sum_d dv[d] W_edge[c,d]
-__global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const double *__restrict__ part, int nparts,
-                                                           const float *__restrict__ w_edge, const float *__restrict__ att_edge,
-                                                           int H, int edge_dim, float *__restrict__ dw_edge,
-                                                           float *__restrict__ datt_edge, int accumulate)
+struct EdgeVecJobs {                                                // per layer (blockIdx.x): the edge projection and its gradient buffers
+    const float *w_edge[NSC_GAT_MAX_LAYERS], *att_edge[NSC_GAT_MAX_LAYERS];
+    float *dw_edge[NSC_GAT_MAX_LAYERS], *datt_edge[NSC_GAT_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const double *__restrict__ part_all, int nparts, EdgeVecJobs jobs,
+                                                           int H, int edge_dim, int accumulate)
 {
+    const int l = blockIdx.x;
+    const double *__restrict__ part = part_all + (long long)l * EDGE_BWD_WGS * NSC_GAT_MAX_EDGE_DIM;
+    const float *__restrict__ w_edge = jobs.w_edge[l], *__restrict__ att_edge = jobs.att_edge[l];
+    float *__restrict__ dw_edge = jobs.dw_edge[l], *__restrict__ datt_edge = jobs.datt_edge[l];
+    if (!dw_edge || !datt_edge) return;                             // (a layer without an edge projection)
     __shared__ float dv[NSC_GAT_MAX_EDGE_DIM];
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;                        // lane g holds partial g (nparts <= 64)
@@ -1335,7 +1391,7 @@ struct TrainWs {
     // saved by the forward
     size_t z0, mean0, invstd0, h, g, a_src, a_dst, alpha, y, mean, invstd, vvec;
     // backward scratch
-    size_t dh, dh2, dv, dg, draw, da_src, da_dst, s1, s2, dvvec, slabs, slab_cap, colpart, colpart2, total;
+    size_t dh, dh2, dv, dg, draw, edgepart, da_src, da_dst, s1, s2, dvvec, slabs, slab_cap, colpart, colpart2, colpart2_stride, attpart, attpart_stride, colpart_ob, total;
     size_t nh, nn, hh, nz;
 };
 
@@ -1362,9 +1418,10 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     w.dh2 = o; o += w.nh;
     w.dv = o; o += w.nh;
     w.dg = o; o += w.nh;
-    w.draw = o; o += w.nz;
-    w.da_src = o; o += w.nn;
-    w.da_dst = o; o += w.nn;
+    w.draw = o; o += w.nz * L;                                      // per layer: the edge terms of all layers are reduced in one launch at the end
+    w.edgepart = o; o += align256((size_t)NSC_GAT_MAX_LAYERS * EDGE_BWD_WGS * NSC_GAT_MAX_EDGE_DIM * 8);
+    w.da_src = o; o += w.nn * L;                                    // per layer: reduced against G at the end of the backward
+    w.da_dst = o; o += w.nn * L;
     w.s1 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
     w.s2 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
     w.dvvec = o; o += 256;
@@ -1377,7 +1434,11 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     w.slab_cap = all_w * SPLITK_SLABS + 64 * SLAB_JOBS;            // floats
     o += align256(w.slab_cap * 4);
     w.colpart = o; o += align256((size_t)COLRED_MAXR * std::max(std::max(H, m->out_dim), m->in_dim) * 2 * 8);
-    w.colpart2 = o; o += align256((size_t)COLRED_MAXR * H * 8);      // partials of the bias gradient (bn_apply_colsum_kernel)
+    w.colpart2_stride = align256((size_t)COLRED_MAXR * H * 8);      // partials of a bias gradient (bn_apply_colsum_kernel): one slot
+    w.colpart2 = o; o += w.colpart2_stride * (L + 1);               // per BatchNorm, their finals run together at the end
+    w.attpart_stride = align256((size_t)COLRED_MAXR * H * 2 * 8);   // partials of a layer's two attention-vector gradients
+    w.attpart = o; o += w.attpart_stride * L;
+    w.colpart_ob = o; o += align256((size_t)COLRED_MAXR * m->out_dim * 2 * 8);   // partials of the output bias gradient
     w.total = o;
     return w;
 }
@@ -1648,8 +1709,19 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     char *b = static_cast<char *>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(b + off); };
     double *colpart = reinterpret_cast<double *>(b + w.colpart);
-    double *colpart2 = reinterpret_cast<double *>(b + w.colpart2);
+    auto colpart2 = [&](int slot) { return reinterpret_cast<double *>(b + w.colpart2 + w.colpart2_stride * slot); };
     float *slabs = F(w.slabs);
+    // what nothing inside the backward reads is reduced at its END, in batched launches: the final passes of every column sum
+    // (colreduce_final_jobs_kernel), the attention-vector sums of all layers (colreduce_partial_layers_kernel), the edge terms,
+    // the slab sums of the weight gradients
+    ColFinalJobs fin = {};
+    ColPartJobs attp = {};
+    const int Rn = colred_rows(N), rows_n = (N + Rn - 1) / Rn;
+    auto push_final = [&](const double *part, int C, const ColFinal &f, const ColExtra &x) {
+        const int k = fin.n++;
+        fin.part[k] = part; fin.R[k] = Rn; fin.C[k] = C; fin.f[k] = f; fin.x[k] = x;
+    };
+    const ColExtra no_extra = {nullptr, 0, 0, nullptr};
     SlabDefer defer_ = {};
     {
         size_t big = (size_t)std::max(Din, Dout) * H;
@@ -1658,6 +1730,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         defer_.cap = w.slab_cap;
     }
     SlabDefer *defer = &defer_;
+    EdgeVecJobs edge_jobs = {};
+    bool any_edge = false;
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
     const long long NH = (long long)N * H;
     const int splits = N >= 512 ? SPLITK_SLABS : 1;
@@ -1666,7 +1740,13 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     const int acc = cfg->accumulate_grads ? 1 : 0;
 
     // output_proj: out = h_L W_out^T + b (+ x)
-    colreduce(st, grad_out, nullptr, nullptr, nullptr, nullptr, N, Dout, colpart, 0, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr, acc);
+    {
+        double *ob = reinterpret_cast<double *>(b + w.colpart_ob);
+        hipLaunchKernelGGL(colreduce_partial_kernel, dim3((Dout + 63) / 64, Rn), dim3(256), 0, st, grad_out, static_cast<const float *>(nullptr),
+                           static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), static_cast<const float *>(nullptr),
+                           N, Dout, rows_n, ob, static_cast<const float *>(nullptr));
+        push_final(ob, Dout, ColFinal{0, N, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr, acc, 0, nullptr, nullptr, 0}, no_extra);
+    }
     gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, acc, splits, slabs, defer);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
     gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, slabs);   // dh_L = dOut W_out
@@ -1702,7 +1782,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         // its partials come out of the apply pass, its final rides along the attention-vector reduction below
         const ColExtra bias_x = bn_backward(st, dh, y, mean, invstd, Ly.bn_w, Ly.bn_b, act, act ? cfg->dropout_p : 0.0f,
                                             SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}, 200u + l,
-                                            N, H, dv, s1, s2, Gl.bn_b, Gl.bn_w, acc, colpart, colpart2, Gl.bias);
+                                            N, H, dv, s1, s2, Gl.bn_b, Gl.bn_w, acc, colpart, colpart2(l), Gl.bias);
         float *dY = dv;
         // attention backward
         AttBwdA A;
@@ -1710,7 +1790,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         A.loop_attr = use_edge ? g->loop_attr : nullptr; A.edge_attr = use_edge ? edge_attr : nullptr;
         A.v = use_edge ? vv : nullptr;
         A.a_src = as; A.a_dst = ad; A.G = G; A.alpha = alpha; A.dY = dY;
-        A.draw = F(w.draw); A.da_dst = F(w.da_dst);
+        A.draw = F(w.draw + w.nz * l); A.da_dst = F(w.da_dst + w.nn * l);
         A.slope = m->negative_slope; A.p = cfg->dropout_p; A.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; A.stream = 100u + l;
         A.N = N; A.H = H; A.edge_dim = m->edge_dim;
         switch ((H + 255) / 256) {
@@ -1721,8 +1801,8 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         }
         AttBwdB Bk;
         Bk.t_ptr = g->t_ptr; Bk.t_entry = g->t_entry; Bk.tgt = g->tgt;
-        Bk.alpha = alpha; Bk.dY = dY; Bk.draw = F(w.draw); Bk.da_dst = F(w.da_dst);
-        Bk.att_src = Ly.att_src; Bk.att_dst = Ly.att_dst; Bk.dG = dG; Bk.da_src = F(w.da_src);
+        Bk.alpha = alpha; Bk.dY = dY; Bk.draw = F(w.draw + w.nz * l); Bk.da_dst = F(w.da_dst + w.nn * l);
+        Bk.att_src = Ly.att_src; Bk.att_dst = Ly.att_dst; Bk.dG = dG; Bk.da_src = F(w.da_src + w.nn * l);
         Bk.p = cfg->dropout_p; Bk.seed = SeedRef{cfg->seed, reinterpret_cast<const unsigned long long *>(cfg->seed_dev)}; Bk.stream = 100u + l; Bk.N = N; Bk.H = H;
         switch ((H + 255) / 256) {
         case 1: hipLaunchKernelGGL(att_bwd_source_kernel<1>, dim3((N + 3) / 4), dim3(256), 0, st, Bk); break;
@@ -1731,14 +1811,17 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         default: hipLaunchKernelGGL(att_bwd_source_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, st, Bk); break;
         }
         // datt_src = sum_j da_src[j] g_j ; datt_dst = sum_j da_dst[j] g_j
-        colreduce(st, G, F(w.da_src), nullptr, nullptr, nullptr, N, H, colpart, 0, 0.f, 0.f, Gl.att_src, Gl.att_dst, nullptr, nullptr, acc,
-                  acc, nullptr, nullptr, 0, F(w.da_dst), bias_x);
+        // (at the end of the backward, with the other layers': the conv-bias final rides along this layer's final)
+        {
+            double *ap = reinterpret_cast<double *>(b + w.attpart + w.attpart_stride * l);
+            attp.P[l] = G; attp.w[l] = F(w.da_src + w.nn * l); attp.w2[l] = F(w.da_dst + w.nn * l); attp.part[l] = ap;
+            push_final(ap, H, ColFinal{0, N, 0.f, 0.f, Gl.att_src, Gl.att_dst, nullptr, nullptr, acc, acc, nullptr, nullptr, 0}, bias_x);
+        }
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
-            if (use_edge) {
-                hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt,
-                                   g->loop_attr, edge_attr, F(w.draw), N, m->edge_dim, colpart);
-                hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(1), dim3(256), 0, st, colpart, EDGE_BWD_WGS, Ly.lin_edge_w, Ly.att_edge,
-                                   H, m->edge_dim, Gl.lin_edge_w, Gl.att_edge, acc);
+            if (use_edge) {                         // reduced with the other layers' at the end (edge_term_bwd_kernel over all layers)
+                edge_jobs.w_edge[l] = Ly.lin_edge_w; edge_jobs.att_edge[l] = Ly.att_edge;
+                edge_jobs.dw_edge[l] = Gl.lin_edge_w; edge_jobs.datt_edge[l] = Gl.att_edge;
+                any_edge = true;
             } else if (!acc) {                      // no edge term in this forward: zero gradient (nothing to add when accumulating)
                 fill_zero(st, Gl.lin_edge_w, (long long)H * m->edge_dim);
                 fill_zero(st, Gl.att_edge, H);
@@ -1752,11 +1835,20 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     }
     // h_0 = relu(bn(z0)),  z0 = x W_in^T + b_in
     float *dv = F(w.dv), *s1 = F(w.s1), *s2 = F(w.s2);
-    bias_final(st, H, bn_backward(st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u,
-                                  N, H, dv, s1, s2, gr->in_bn_b, gr->in_bn_w, acc, colpart, colpart2, gr->in_b));
+    push_final(nullptr, H, ColFinal{0, 0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0},
+               bn_backward(st, dh, F(w.z0), F(w.mean0), F(w.invstd0), m->in_bn_w, m->in_bn_b, 1, 0.0f, SeedRef{0ull, nullptr}, 0u,
+                           N, H, dv, s1, s2, gr->in_bn_b, gr->in_bn_w, acc, colpart, colpart2(L), gr->in_b));
     gemm<true, true>(st, dv, H, x, Din, H, Din, N, gr->in_w, Din, nullptr, acc, splits, slabs, defer);
     if (gr->x) {   // + dZ0 W_in
         gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, slabs);
+    }
+    hipLaunchKernelGGL(colreduce_partial_layers_kernel, dim3((H + 63) / 64, Rn, L), dim3(256), 0, st, attp, N, H, rows_n);
+    hipLaunchKernelGGL(colreduce_final_jobs_kernel, dim3((std::max(H, Dout) + 63) / 64, fin.n), dim3(256), 0, st, fin);
+    if (any_edge) {                                                 // d lin_edge / d att_edge of every layer: two launches in all
+        double *ep = reinterpret_cast<double *>(b + w.edgepart);
+        hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS, L), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt, g->loop_attr,
+                           edge_attr, F(w.draw), (long long)(w.nz / 4), N, m->edge_dim, ep);
+        hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(L), dim3(256), 0, st, ep, EDGE_BWD_WGS, edge_jobs, H, m->edge_dim, acc);
     }
     slab_defer_flush(st, defer);                                    // every weight gradient's slab sum, one launch
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;

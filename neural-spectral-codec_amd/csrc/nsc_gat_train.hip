@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     out[i] = accumulate ? out[i] + s : s;
 }
 
-// The slab sums of ALL weight-gradient products of a backward in ONE launch (round 4): nothing inside the backward reads a weight
+// The slab sums of ALL weight-gradient products of a backward together, in the backward's last launch (round 4): nothing inside the backward reads a weight
 // gradient, so every product keeps its slabs in a region of its own and the sums -- same fixed order, same (out + s) -- run once at
 // the end: five 5 us launches per batch become one.
 struct SlabJob {
@@ -229,27 +229,24 @@ inline void slab_defer_push(SlabDefer *d, const float *part, float *out, long lo
     d->b.blocks += (unsigned)((MN + 255) / 256);
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabBatch b)
+__device__ __forceinline__ void slab_reduce_multi_body(const SlabBatch &b, unsigned bid)
 {
     int j = 0;
 #pragma unroll
     for (int t = 1; t < SLAB_JOBS; ++t)
-        if (t < b.n && blockIdx.x >= b.j[t].blk0) j = t;
+        if (t < b.n && bid >= b.j[t].blk0) j = t;
     const float *__restrict__ part = b.j[j].part;
     float *__restrict__ out = b.j[j].out;
     const long long MN = b.j[j].MN;
     const int S = b.j[j].S;
-    const long long i = (long long)(blockIdx.x - b.j[j].blk0) * 256 + threadIdx.x;
+    const long long i = (long long)(bid - b.j[j].blk0) * 256 + threadIdx.x;
     if (i >= MN) return;
     float s = 0.0f;
     for (int z = 0; z < S; ++z) s += part[(long long)z * MN + i];     // fixed order: deterministic
     out[i] = b.j[j].accumulate ? out[i] + s : s;
 }
 
-inline void slab_defer_flush(hipStream_t st, SlabDefer *d)
-{
-    if (d && d->b.n > 0) hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(d->b.blocks), dim3(256), 0, st, d->b);
-}
+
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradients  dW[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands k-major (dW = dY^T X: the rows of dY and X are the
@@ -521,14 +518,14 @@ __device__ __forceinline__ void colreduce_partial_body(const float *__restrict__
                                                        const float *__restrict__ Q, const float *__restrict__ qm,
                                                        const float *__restrict__ qs, int N, int C,
                                                        int rows_per_block, double *__restrict__ part,
-                                                       const float *__restrict__ w2)
+                                                       const float *__restrict__ w2, int bx, int by)
 {
     // w2 (with Q null): out_b[c] = sum_n P[n][c] * w2[n] -- the two attention-vector gradients of a layer read the same
-    // matrix with two weight vectors: one pass instead of two
+    // matrix with two weight vectors: one pass instead of two.  (bx, by): column block and row block of this workgroup
     __shared__ double sa[256], sb[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+    const int c = bx * 64 + cx;
+    const int n0 = by * rows_per_block, n1 = min(N, n0 + rows_per_block);
     double a = 0.0, b = 0.0;
     if (c < C) {
         const float m = qm ? qm[c] : 0.0f, s = qs ? qs[c] : 1.0f;
@@ -562,8 +559,8 @@ __device__ __forceinline__ void colreduce_partial_body(const float *__restrict__
     if (ry == 0 && c < C) {
         a = sa[cx] + sa[64 + cx] + sa[128 + cx] + sa[192 + cx];
         b = sb[cx] + sb[64 + cx] + sb[128 + cx] + sb[192 + cx];
-        part[((long long)blockIdx.y * C + c) * 2] = a;
-        part[((long long)blockIdx.y * C + c) * 2 + 1] = b;
+        part[((long long)by * C + c) * 2] = a;
+        part[((long long)by * C + c) * 2 + 1] = b;
     }
 }
 
@@ -573,21 +570,16 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(const float *__r
                                                                 int rows_per_block, double *__restrict__ part,
                                                                 const float *__restrict__ w2)
 {
-    colreduce_partial_body(P, w, Q, qm, qs, N, C, rows_per_block, part, w2);
+    colreduce_partial_body(P, w, Q, qm, qs, N, C, rows_per_block, part, w2, blockIdx.x, blockIdx.y);
 }
 
 // The attention-vector gradients of ALL layers (datt_src = sum_j da_src[j] g_j, datt_dst likewise: two weighted column sums of
-// the layer's saved G) in one launch at the end of the backward, blockIdx.z = layer (round 4: nothing inside the backward reads
+// the layer's saved G) at the end of the backward (backward_end_partials_kernel; round 4: nothing inside the backward reads
 // them; every layer keeps its da_src / da_dst and its partials in buffers of its own).
 struct ColPartJobs {
     const float *P[NSC_GAT_MAX_LAYERS], *w[NSC_GAT_MAX_LAYERS], *w2[NSC_GAT_MAX_LAYERS];
     double *part[NSC_GAT_MAX_LAYERS];
 };
-__global__ __launch_bounds__(256) void colreduce_partial_layers_kernel(ColPartJobs j, int N, int C, int rows_per_block)
-{
-    const int l = blockIdx.z;
-    colreduce_partial_body(j.P[l], j.w[l], nullptr, nullptr, nullptr, N, C, rows_per_block, j.part[l], j.w2[l]);
-}
 
 // A second, one-component sum that rides along a final pass (round 4): out[c] (+)= sum_r part[r][c], float64 partials of
 // ANOTHER matrix written by an earlier kernel of the stream (the conv / input bias gradient, whose pass 1 is fused into
@@ -600,11 +592,11 @@ struct ColExtra {
 
 // Pass 2: the R partial rows of a 64-column block, summed in fixed order (deterministic), then the finish (ColFinal).
 __device__ __forceinline__ void colreduce_final_body(const double *__restrict__ part, int R, int C, const ColFinal &f,
-                                                     const ColExtra &x)
+                                                     const ColExtra &x, int bx)
 {
     __shared__ double sa[256], sb[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    const int c = bx * 64 + cx;
     if (part) colreduce_finish(part, R, C, c, cx, ry, sa, sb, f);
     if (x.part) {
         __syncthreads();                                   // (sa is reused; the threads that left colreduce_finish early are back)
@@ -623,10 +615,10 @@ __device__ __forceinline__ void colreduce_final_body(const double *__restrict__ 
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const double *__restrict__ part, int R, int C, ColFinal f,
                                                               ColExtra x)
 {
-    colreduce_final_body(part, R, C, f, x);
+    colreduce_final_body(part, R, C, f, x, blockIdx.x);
 }
 
-// Every final pass a backward has left for its end, one launch (blockIdx.y = job): the attention-vector gradients of the layers
+// Every final pass a backward has left for its end (backward_end_finals_kernel): the attention-vector gradients of the layers
 // with the conv-bias finals riding along, the output bias, the input bias.
 constexpr int COL_JOBS = NSC_GAT_MAX_LAYERS + 2;
 struct ColFinalJobs {
@@ -636,12 +628,6 @@ struct ColFinalJobs {
     ColExtra x[COL_JOBS];
     int n;
 };
-__global__ __launch_bounds__(256) void colreduce_final_jobs_kernel(ColFinalJobs j)
-{
-    const int l = blockIdx.y;
-    if ((int)blockIdx.x * 64 >= j.C[l]) return;                     // (workgroup-uniform: ahead of every barrier)
-    colreduce_final_body(j.part[l], j.R[l], j.C[l], j.f[l], j.x[l]);
-}
 
 // BatchNorm backward, pass 1, with the activation backward fused in (round 4: bn_act_bwd_dv_kernel + colreduce_partial_kernel
 // were two launches and two passes over the (N, C) matrix):  dV = dH * dropmask * relu'(v) is computed on the fly (v from z
@@ -1206,24 +1192,28 @@ __global__ __launch_bounds__(256) void att_bwd_source_kernel(AttBwdB a)
 // tiny kernel adds them in workgroup order -> deterministic
 constexpr int EDGE_BWD_WGS = 64;
 
-__global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restrict__ row_ptr,
-                                                            const int *__restrict__ eid,
-                                                            const int *__restrict__ tgt,
-                                                            const float *__restrict__ loop_attr,
-                                                            const float *__restrict__ edge_attr,
-                                                            const float *__restrict__ draw_all, long long draw_stride,
-                                                            int N, int edge_dim, double *__restrict__ part_all)
+struct EdgeTermArgs {
+    const int *row_ptr, *eid, *tgt;
+    const float *loop_attr, *edge_attr, *draw_all;
+    long long draw_stride;                                          // floats between two layers' d logit / d raw buffers
+    int N, edge_dim;
+    double *part_all;
+};
+// workgroup bx of EDGE_BWD_WGS, layer l (round 4: the edge terms of ALL layers at the end of the backward; every layer keeps its
+// d logit / d raw in a buffer of its own)
+__device__ __forceinline__ void edge_term_bwd_body(const EdgeTermArgs &a, int bx, int l)
 {
-    // blockIdx.y = layer (round 4: the edge terms of ALL layers in one launch at the end of the backward; every layer keeps its
-    // d logit / d raw in a buffer of its own)
-    const float *__restrict__ draw = draw_all + (long long)blockIdx.y * draw_stride;
-    double *__restrict__ part = part_all + (long long)blockIdx.y * EDGE_BWD_WGS * NSC_GAT_MAX_EDGE_DIM;
+    const int *__restrict__ row_ptr = a.row_ptr, *__restrict__ eid = a.eid, *__restrict__ tgt = a.tgt;
+    const float *__restrict__ loop_attr = a.loop_attr, *__restrict__ edge_attr = a.edge_attr;
+    const int N = a.N, edge_dim = a.edge_dim;
+    const float *__restrict__ draw = a.draw_all + (long long)l * a.draw_stride;
+    double *__restrict__ part = a.part_all + (long long)l * EDGE_BWD_WGS * NSC_GAT_MAX_EDGE_DIM;
     __shared__ double sh[256];
     const int nnz = row_ptr[N];
     double s[NSC_GAT_MAX_EDGE_DIM];
 #pragma unroll
     for (int d = 0; d < NSC_GAT_MAX_EDGE_DIM; ++d) s[d] = 0.0;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nnz; e += gridDim.x * 256) {
+    for (int e = bx * 256 + threadIdx.x; e < nnz; e += EDGE_BWD_WGS * 256) {
         const int id = eid[e];
         const float *ea = id >= 0 ? edge_attr + (long long)id * edge_dim : loop_attr + (long long)tgt[e] * edge_dim;
         const double dr = (double)draw[e];
@@ -1237,22 +1227,21 @@ __global__ __launch_bounds__(256) void edge_term_bwd_kernel(const int *__restric
         sh[threadIdx.x] = s[d];
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-        if (threadIdx.x == 0) part[blockIdx.x * NSC_GAT_MAX_EDGE_DIM + d] = sh[0];
+        if (threadIdx.x == 0) part[bx * NSC_GAT_MAX_EDGE_DIM + d] = sh[0];
         __syncthreads();
     }
 }
 
-// (round 4: one launch instead of edge_term_bwd_final_kernel + edge_vec_bwd_kernel)  dv[d] = sum of the workgroups' partials in a
+// (one workgroup per layer)  dv[d] = sum of the workgroups' partials in a
 // fixed shuffle tree (deterministic), then the backward of v = W_edge^T att_edge: dW_edge[c,d] = dv[d] att_edge[c],
 // datt_edge[c] = sum_d dv[d] W_edge[c,d]
 struct EdgeVecJobs {                                                // per layer (blockIdx.x): the edge projection and its gradient buffers
     const float *w_edge[NSC_GAT_MAX_LAYERS], *att_edge[NSC_GAT_MAX_LAYERS];
     float *dw_edge[NSC_GAT_MAX_LAYERS], *datt_edge[NSC_GAT_MAX_LAYERS];
 };
-__global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const double *__restrict__ part_all, int nparts, EdgeVecJobs jobs,
-                                                           int H, int edge_dim, int accumulate)
+__device__ __forceinline__ void edge_vec_bwd_body(const double *__restrict__ part_all, int nparts, const EdgeVecJobs &jobs,
+                                                  int H, int edge_dim, int accumulate, int l)
 {
-    const int l = blockIdx.x;
     const double *__restrict__ part = part_all + (long long)l * EDGE_BWD_WGS * NSC_GAT_MAX_EDGE_DIM;
     const float *__restrict__ w_edge = jobs.w_edge[l], *__restrict__ att_edge = jobs.att_edge[l];
     float *__restrict__ dw_edge = jobs.dw_edge[l], *__restrict__ datt_edge = jobs.datt_edge[l];
@@ -1276,6 +1265,51 @@ __global__ __launch_bounds__(256) void edge_vec_bwd_kernel(const double *__restr
             s = __builtin_fmaf(dv[d], w_edge[(long long)c * edge_dim + d], s);
         }
         datt_edge[c] = accumulate ? datt_edge[c] + s : s;
+    }
+}
+
+// The end of a backward in TWO launches (round 4): what nothing inside the backward reads -- the attention-vector gradients of
+// all layers, the edge-term gradients of all layers, every column sum's final pass, the slab sums of the five weight gradients
+// -- used to be 4 + 2 + 2 launches per layer and five more; they are independent pieces of work of the same workgroup shape, so
+// they share a grid: a workgroup finds its piece by its index range.  Every piece computes exactly what its own kernel did.
+struct EndPartials {
+    ColPartJobs att;                                                // workgroups [0, n_att): (column block, row block, layer)
+    int N, C, rows, nbx, R;
+    unsigned n_att;
+    EdgeTermArgs edge;                                              // then EDGE_BWD_WGS per layer
+};
+__global__ __launch_bounds__(256) void backward_end_partials_kernel(EndPartials p)
+{
+    unsigned b = blockIdx.x;
+    if (b < p.n_att) {
+        const int bx = (int)(b % (unsigned)p.nbx), t = (int)(b / (unsigned)p.nbx), by = t % p.R, l = t / p.R;
+        colreduce_partial_body(p.att.P[l], p.att.w[l], nullptr, nullptr, nullptr, p.N, p.C, p.rows, p.att.part[l], p.att.w2[l], bx, by);
+    } else {
+        b -= p.n_att;
+        edge_term_bwd_body(p.edge, (int)(b % EDGE_BWD_WGS), (int)(b / EDGE_BWD_WGS));
+    }
+}
+
+struct EndFinals {
+    ColFinalJobs fin;                                               // workgroups [0, n_fin): (column block, job)
+    int nbx;
+    unsigned n_fin, n_edge;                                         // then one workgroup per layer with an edge projection,
+    EdgeVecJobs ev;                                                 // then the slab sums
+    const double *edge_part;
+    int H, edge_dim, accumulate;
+    SlabBatch slabs;
+};
+__global__ __launch_bounds__(256) void backward_end_finals_kernel(EndFinals p)
+{
+    unsigned b = blockIdx.x;
+    if (b < p.n_fin) {
+        const int bx = (int)(b % (unsigned)p.nbx), l = (int)(b / (unsigned)p.nbx);
+        if (bx * 64 >= p.fin.C[l]) return;                          // (workgroup-uniform: ahead of every barrier)
+        colreduce_final_body(p.fin.part[l], p.fin.R[l], p.fin.C[l], p.fin.f[l], p.fin.x[l], bx);
+    } else if (b < p.n_fin + p.n_edge) {
+        edge_vec_bwd_body(p.edge_part, EDGE_BWD_WGS, p.ev, p.H, p.edge_dim, p.accumulate, (int)(b - p.n_fin));
+    } else {
+        slab_reduce_multi_body(p.slabs, b - p.n_fin - p.n_edge);
     }
 }
 
@@ -1428,7 +1462,7 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     size_t big = (size_t)std::max(m->in_dim, m->out_dim) * H;
     if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
     w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);            // region 0: a product that sums its slabs at once, transposed weights
-    // ... and a region per weight-gradient product of a backward whose sums wait for the batched launch (slab_reduce_multi_kernel)
+    // ... and a region per weight-gradient product of a backward whose sums wait for the backward's last launch (backward_end_finals_kernel)
     size_t all_w = (size_t)m->in_dim * H + (size_t)m->out_dim * H + (size_t)L * H * H;
     if (m->residual && m->in_dim != m->out_dim) all_w += (size_t)m->in_dim * m->out_dim;
     w.slab_cap = all_w * SPLITK_SLABS + 64 * SLAB_JOBS;            // floats
@@ -1466,8 +1500,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // buffer, free between two weight-gradient products of the stream, takes the transposed weight.
 template <bool AKM, bool BKM>
 void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int M, int N, int K, float *C, int ldc,
-          const float *bias, int accumulate, int splits, float *slabs, SlabDefer *defer = nullptr)
+          const float *bias, int accumulate, int splits, float *slabs, SlabDefer *defer = nullptr, const float *resid = nullptr)
 {
+    // resid (non-accumulating single-slice products only, same leading dimension as C): C = product + resid, in the epilogue of
+    // the LDS-DMA GEMM where that kernel takes the product (the backward's dh_{l} = dG W + dh_{l+1} residual path), by an
+    // add_inplace_kernel behind any other form -- the same two roundings either way
     if (!AKM && splits <= 1 && (!BKM || (slabs && !(K & 15) && !(reinterpret_cast<unsigned long long>(slabs) & 15)))) {
         // the projections of the training forward, and the dX = dY W products of the backward through a transposed copy of
         // the weight (0.8 MB at most: a 3 us kernel): the inference forward's LDS-DMA GEMM -- same chain per output element
@@ -1480,6 +1517,7 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
             GemmEpi e0 = {};
             e0.bias = bias;
             if (accumulate) { e0.resid = C; e0.ldr = ldc; }
+            else if (resid) { e0.resid = resid; e0.ldr = ldc; }
             if (launch_glds_bkm(st, A, lda, B, ldb, M, N, K, C, ldc, e0)) return;
         }
         if (BKM) {
@@ -1490,6 +1528,7 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
         GemmEpi ep = {};
         ep.bias = bias;
         if (accumulate) { ep.resid = C; ep.ldr = ldc; }
+        else if (resid) { ep.resid = resid; ep.ldr = ldc; }
         if (launch_glds<2>(st, A, lda, Bn, ldn, nullptr, M, N, N, K, C, ldc, ep)) return;
     }
     if (AKM && BKM && splits > 1 && !bias && ldc == N && launch_tn_glds(st, A, lda, B, ldb, M, N, K, C, accumulate, slabs, SPLITK_SLABS, defer))
@@ -1508,6 +1547,8 @@ void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, int 
         if (own) slab_defer_push(defer, own, C, MN, splits, accumulate);
         else hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, slabs, splits, MN, C, accumulate);
     }
+    if (resid && !accumulate && ldc == N)
+        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, C, resid, (long long)M * N);
 }
 
 inline int colred_rows(int N)
@@ -1712,7 +1753,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     auto colpart2 = [&](int slot) { return reinterpret_cast<double *>(b + w.colpart2 + w.colpart2_stride * slot); };
     float *slabs = F(w.slabs);
     // what nothing inside the backward reads is reduced at its END, in batched launches: the final passes of every column sum
-    // (colreduce_final_jobs_kernel), the attention-vector sums of all layers (colreduce_partial_layers_kernel), the edge terms,
+    // (in backward_end_finals_kernel), the attention-vector sums of all layers (in backward_end_partials_kernel), the edge terms,
     // the slab sums of the weight gradients
     ColFinalJobs fin = {};
     ColPartJobs attp = {};
@@ -1733,7 +1774,6 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     EdgeVecJobs edge_jobs = {};
     bool any_edge = false;
     const bool use_edge = m->edge_dim > 0 && edge_attr && g->loop_attr;
-    const long long NH = (long long)N * H;
     const int splits = N >= 512 ? SPLITK_SLABS : 1;
     // NscGatTrainCfg.accumulate_grads: every PARAMETER gradient is added to what its buffer holds (gradient accumulation
     // over the batches of an optimizer step without a pass of axpy kernels behind the backward); gr->x is always overwritten
@@ -1818,7 +1858,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
             push_final(ap, H, ColFinal{0, N, 0.f, 0.f, Gl.att_src, Gl.att_dst, nullptr, nullptr, acc, acc, nullptr, nullptr, 0}, bias_x);
         }
         if (m->edge_dim > 0 && Gl.lin_edge_w && Gl.att_edge) {
-            if (use_edge) {                         // reduced with the other layers' at the end (edge_term_bwd_kernel over all layers)
+            if (use_edge) {                         // reduced with the other layers' at the end (backward_end_partials_kernel)
                 edge_jobs.w_edge[l] = Ly.lin_edge_w; edge_jobs.att_edge[l] = Ly.att_edge;
                 edge_jobs.dw_edge[l] = Gl.lin_edge_w; edge_jobs.datt_edge[l] = Gl.att_edge;
                 any_edge = true;
@@ -1829,8 +1869,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         }
         // g = h_l W^T :  dW = dG^T h_l ,  dh_l = dG W (+ residual path)
         gemm<true, true>(st, dG, H, hin, H, H, H, N, Gl.lin_w, H, nullptr, acc, splits, slabs, defer);
-        gemm<false, true>(st, dG, H, Ly.lin_w, H, N, H, H, dh_prev, H, nullptr, 0, 1, slabs);
-        if (has_res) hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks(NH)), dim3(256), 0, st, dh_prev, dh, NH);
+        gemm<false, true>(st, dG, H, Ly.lin_w, H, N, H, H, dh_prev, H, nullptr, 0, 1, slabs, nullptr, has_res ? dh : nullptr);
         float *t = dh; dh = dh_prev; dh_prev = t;
     }
     // h_0 = relu(bn(z0)),  z0 = x W_in^T + b_in
@@ -1842,15 +1881,20 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     if (gr->x) {   // + dZ0 W_in
         gemm<false, true>(st, dv, H, m->in_w, Din, N, Din, H, gr->x, Din, nullptr, 1, 1, slabs);
     }
-    hipLaunchKernelGGL(colreduce_partial_layers_kernel, dim3((H + 63) / 64, Rn, L), dim3(256), 0, st, attp, N, H, rows_n);
-    hipLaunchKernelGGL(colreduce_final_jobs_kernel, dim3((std::max(H, Dout) + 63) / 64, fin.n), dim3(256), 0, st, fin);
-    if (any_edge) {                                                 // d lin_edge / d att_edge of every layer: two launches in all
+    {
         double *ep = reinterpret_cast<double *>(b + w.edgepart);
-        hipLaunchKernelGGL(edge_term_bwd_kernel, dim3(EDGE_BWD_WGS, L), dim3(256), 0, st, g->row_ptr, g->eid, g->tgt, g->loop_attr,
-                           edge_attr, F(w.draw), (long long)(w.nz / 4), N, m->edge_dim, ep);
-        hipLaunchKernelGGL(edge_vec_bwd_kernel, dim3(L), dim3(256), 0, st, ep, EDGE_BWD_WGS, edge_jobs, H, m->edge_dim, acc);
+        EndPartials pa = {};
+        pa.att = attp; pa.N = N; pa.C = H; pa.rows = rows_n; pa.nbx = (H + 63) / 64; pa.R = Rn;
+        pa.n_att = (unsigned)(pa.nbx * Rn * L);
+        pa.edge = EdgeTermArgs{g->row_ptr, g->eid, g->tgt, g->loop_attr, edge_attr, F(w.draw), (long long)(w.nz / 4), N, m->edge_dim, ep};
+        hipLaunchKernelGGL(backward_end_partials_kernel, dim3(pa.n_att + (any_edge ? (unsigned)(EDGE_BWD_WGS * L) : 0u)), dim3(256), 0, st, pa);
+        EndFinals fa = {};
+        fa.fin = fin; fa.nbx = (std::max(H, Dout) + 63) / 64;
+        fa.n_fin = (unsigned)(fa.nbx * fin.n); fa.n_edge = any_edge ? (unsigned)L : 0u;
+        fa.ev = edge_jobs; fa.edge_part = ep; fa.H = H; fa.edge_dim = m->edge_dim; fa.accumulate = acc;
+        fa.slabs = defer->b;                                        // (the weight gradients' slab sums: after the last product above)
+        hipLaunchKernelGGL(backward_end_finals_kernel, dim3(fa.n_fin + fa.n_edge + defer->b.blocks), dim3(256), 0, st, fa);
     }
-    slab_defer_flush(st, defer);                                    // every weight gradient's slab sum, one launch
     return hipGetLastError() == hipSuccess ? NSC_OK : NSC_ELAUNCH;
 }
 

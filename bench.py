@@ -357,7 +357,7 @@ def measure_train(dev):
             "step_us": best, "flop_per_step": flop, "per_batch_incl_adam_ms": per_batch_ms,
             "workload": "BASELINE.json configs[4] shape on one GPU: 4541 keyframes, 1024 mined-triplet batch, hidden 256, margin 0.1, "
                         "dropout 0.1: forward (train mode) + TripletLoss + backward as ONE captured hipGraph replay "
-                        "(~70 kernels: the step is launch- and latency-bound, not MFMA-bound); per_batch_incl_adam_ms = "
+                        "(~50 kernels: the step is launch- and latency-bound, not MFMA-bound); per_batch_incl_adam_ms = "
                         "GNNTrainer.train_batches with its optimizer step every 4 batches"}
 
 

@@ -643,3 +643,47 @@ def test_captured_graphs_hold_kernel_nodes_only():
         for cg in made:
             types = node_types(cg)
             assert set(types) == {"kernel"} and types["kernel"] >= 8, types
+
+
+@pytest.mark.parametrize("n_layers,in_dim,out_dim", [(1, 64, 64), (2, 64, 64), (5, 64, 64), (8, 64, 64), (3, 64, 48), (8, 48, 80)])
+def test_other_depths_train_on_the_split_k_path(n_layers, in_dim, out_dim):
+    """The end-of-backward batching (round 4) is sized by NSC_GAT_MAX_LAYERS: depths 1-8 (eight layers + output + input weight
+    = ten slab jobs, two more than the batched launch holds: the last products sum their slabs at once) and residual_proj, at
+    700 nodes -- above the 512 where the weight gradients split K over slabs.  Loss, every parameter gradient and the input
+    gradient against autograd through the restatement."""
+    from neural_spectral_codec_amd.gnn.model import SpectralGNN
+    n = 700
+    torch.manual_seed(6)
+    m = SpectralGNN(input_dim=in_dim, hidden_dim=64, output_dim=out_dim, n_layers=n_layers, dropout=0.0, residual=True, edge_dim=2)
+    go.randomize_bn_stats(m, 7)
+    assert (m.residual_proj is not None) == (in_dim != out_dim)
+    m = m.to("cuda")
+    g = gm.synthetic_chain_graph(n, device="cuda", seed=9, features=torch.rand(n, in_dim))
+    R = torch.randn(n, out_dim, generator=torch.Generator().manual_seed(3))
+    emb_ref, grads_ref, gx_ref, _ = go.reference_gradients(m, g, lambda e: (e * R).sum() + (e * e).sum())
+    m.train()
+    g.x.requires_grad_(True)
+    emb = m(g)
+    ((emb * R.cuda()).sum() + (emb * emb).sum()).backward()
+    emb64 = go.reference_gradients(m, g, lambda e: (e * 0).sum(), dtype=torch.float64)[0]
+    _assert_train_forward(emb, emb_ref, emb64, f"train-mode forward, {n_layers} layers {in_dim}->{out_dim}")
+    tol = 2e-3 * max(1, n_layers // 2)                       # float32 against float32: the error grows with the depth
+    assert _rel(g.x.grad.cpu(), gx_ref) < tol
+    params = dict(m.named_parameters())
+    keys = _key_map(m) + (["residual_proj.weight", "residual_proj.bias"] if m.residual_proj is not None else [])
+    gscale = max(v.abs().max().item() for v in grads_ref.values())
+    for k in keys:
+        got = params[k].grad.detach().cpu().reshape(grads_ref[k].shape)
+        assert torch.isfinite(got).all(), k
+        if k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs."):
+            assert got.abs().max().item() < 1e-3 * gscale * max(1, n_layers // 2), k
+            continue
+        assert _rel(got, grads_ref[k]) < tol, k
+    # a second backward into the same buffers accumulates: exactly twice the gradient (the batched sums add into what is there)
+    first = {k: params[k].grad.detach().clone() for k in keys}
+    g.x.grad = None
+    emb = m(g)
+    ((emb * R.cuda()).sum() + (emb * emb).sum()).backward()
+    for k in keys:
+        if not (k == "input_proj.bias" or k.endswith(".bias") and k.startswith("convs.")):
+            assert _rel(params[k].grad.cpu(), 2 * first[k].cpu()) < 1e-5, k

@@ -99,6 +99,10 @@ def _early_gpus(argv):
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _early_gpus(sys.argv[1:]) > 1:
     sys.exit(self_launch(_early_gpus(sys.argv[1:])))       # before torch is imported: the launcher stays off the GPU
 
+# RCCL's peer access goes through dmabuf IPC on this platform (the host driver has no legacy IPC): must be in the environment
+# before the HIP runtime starts, whoever launched this rank (torch.distributed.run inherits the caller's environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -87,6 +87,28 @@ def self_launch(n_gpus: int) -> int:
     return rc if rc else max((abs(p.returncode) for p in procs), default=0)
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 -> stderr for the duration (libraries that printf to stdout: RCCL's version banner); the C stdio
+    buffer is flushed before the descriptor is restored, or the text would surface on the real stdout at exit."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _early_gpus(argv):
     for i, a in enumerate(argv):
         if a == "--gpus" and i + 1 < len(argv):
@@ -530,21 +552,25 @@ def main():
     # its kernels beside the encoder grid, on the one card a gpurun box has).  Never used for reported numbers.
     rccl1 = world == 1 and os.environ.get("NSC_BENCH_RCCL_WORLD1") == "1"
     multi = world > 1 or rccl1
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rccl1:
-            os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
-        elif rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
     # self-description of the N > 1 line: how many ranks the communicator really joined (an all-reduce of ones), on what
     rccl_ranks, backend = 1, None
     if multi:
-        ones = torch.ones(1, dtype=torch.float32, device=dev)
-        dist.all_reduce(ones)
-        rccl_ranks, backend = int(round(float(ones.item()))), str(dist.get_backend())
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints a five-line version banner on STDOUT when rank 0's communicator comes up (C stdio, not Python's): the
+        # contract is ONE JSON line on stdout, so file descriptor 1 points at stderr until the first collective has run
+        with _stdout_to_stderr():
+            if rccl1:
+                os.environ.setdefault("MASTER_PORT", "29517")
+                dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            elif rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            ones = torch.ones(1, dtype=torch.float32, device=dev)
+            dist.all_reduce(ones)
+            rccl_ranks, backend = int(round(float(ones.item()))), str(dist.get_backend())
+            dist.barrier()
+            torch.cuda.synchronize(dev)
 
     from neural_spectral_codec_amd import synth
     from neural_spectral_codec_amd import distributed as nd

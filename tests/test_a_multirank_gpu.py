@@ -369,8 +369,9 @@ def test_bench_in_the_multi_rank_shape_over_a_one_rank_rccl_group(tmp_path):
     p = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "12", "--warmup", "2", "--clouds", "256"], env=env,
                        capture_output=True, timeout=900, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
-    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, lines
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                 # ONE line on stdout: RCCL's version banner (printed on stdout) went to stderr
+    assert b"RCCL version" in p.stderr
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["backend"] == "nccl"
     assert line["calibration"] is not None and set(k for k in line["calibration"] if k.endswith("_ms_per_step")) == {

@@ -68,7 +68,7 @@ def _key_map(gnn):
     return keys
 
 
-@pytest.mark.parametrize("n,edge_dim", [(40, 2), (300, 2), (300, None), (1500, 2)])
+@pytest.mark.parametrize("n,edge_dim", [(40, 2), (300, 2), (300, None), (1500, 2), (1500, None)])
 def test_forward_train_and_gradients(n, edge_dim):
     m, g, trip = _setup(n, edge_dim)
     ref_model_state = {k: v.clone() for k, v in m.state_dict().items()}

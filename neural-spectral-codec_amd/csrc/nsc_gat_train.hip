@@ -1429,6 +1429,17 @@ struct TrainWs {
     size_t nh, nn, hh, nz;
 };
 
+// floats of ONE slab of the largest weight-gradient product: input / output projection, a layer's H x H lin weight (round 4: this
+// term was missing -- a model whose hidden width exceeds both its input and output widths wrote its lin slabs past the region;
+// every configuration of the path has 800 > 256), residual_proj
+inline size_t slab_region0_floats(const NscGatModel *m)
+{
+    const size_t H = (size_t)m->hidden;
+    size_t big = std::max((size_t)std::max(m->in_dim, m->out_dim) * H, H * H);
+    if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
+    return big;
+}
+
 TrainWs train_ws(const NscGatModel *m, int N, int nnz)
 {
     TrainWs w;
@@ -1459,8 +1470,7 @@ TrainWs train_ws(const NscGatModel *m, int N, int nnz)
     w.s1 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
     w.s2 = o; o += align256((size_t)std::max(H, m->out_dim) * 4);
     w.dvvec = o; o += 256;
-    size_t big = (size_t)std::max(m->in_dim, m->out_dim) * H;
-    if (m->residual && m->in_dim != m->out_dim) big = std::max(big, (size_t)m->in_dim * m->out_dim);   // dW of residual_proj
+    const size_t big = slab_region0_floats(m);
     w.slabs = o; o += align256(big * 4 * SPLITK_SLABS);            // region 0: a product that sums its slabs at once, transposed weights
     // ... and a region per weight-gradient product of a backward whose sums wait for the backward's last launch (backward_end_finals_kernel)
     size_t all_w = (size_t)m->in_dim * H + (size_t)m->out_dim * H + (size_t)L * H * H;
@@ -1765,9 +1775,7 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     const ColExtra no_extra = {nullptr, 0, 0, nullptr};
     SlabDefer defer_ = {};
     {
-        size_t big = (size_t)std::max(Din, Dout) * H;
-        if (m->residual && Din != Dout) big = std::max(big, (size_t)Din * Dout);
-        defer_.base = slabs + align256(big * 4 * SPLITK_SLABS) / 4;
+        defer_.base = slabs + align256(slab_region0_floats(m) * 4 * SPLITK_SLABS) / 4;
         defer_.cap = w.slab_cap;
     }
     SlabDefer *defer = &defer_;

@@ -7,6 +7,7 @@ fused BatchNorm/ReLU/residual epilogues and a wavefront-per-node attention/aggre
 The module must live on a HIP device; there is no CPU fallback.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -120,6 +121,8 @@ def _train_forward_raw(gnn, x, csr, dropout_p, seed):
     out = torch.empty((n, gnn.output_dim), dtype=torch.float32, device=dev)
     nbytes = L.nsc_gat_train_workspace_bytes(C.byref(m), C.byref(g))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # holds the saved activations
+    if os.environ.get("NSC_DEBUG_WS_NAN") == "1":              # debugging: a read of never-written workspace shows up as NaN
+        ws.fill_(0xFF)
     with torch.cuda.device(dev):
         st = L.nsc_gat_forward_train(C.byref(m), C.byref(g), _lib.ptr(x), _lib.ptr(csr.edge_attr),
                                      C.byref(cfg), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))

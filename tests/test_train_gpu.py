@@ -645,16 +645,20 @@ def test_captured_graphs_hold_kernel_nodes_only():
             assert set(types) == {"kernel"} and types["kernel"] >= 8, types
 
 
-@pytest.mark.parametrize("n_layers,in_dim,out_dim", [(1, 64, 64), (2, 64, 64), (5, 64, 64), (8, 64, 64), (3, 64, 48), (8, 48, 80)])
-def test_other_depths_train_on_the_split_k_path(n_layers, in_dim, out_dim):
+@pytest.mark.parametrize("n_layers,in_dim,out_dim,hidden", [(1, 64, 64, 64), (2, 64, 64, 64), (5, 64, 64, 64), (8, 64, 64, 64),
+                                                            (3, 64, 48, 64), (8, 48, 80, 64), (4, 64, 96, 128), (8, 64, 64, 128)])
+def test_other_depths_train_on_the_split_k_path(n_layers, in_dim, out_dim, hidden):
     """The end-of-backward batching (round 4) is sized by NSC_GAT_MAX_LAYERS: depths 1-8 (eight layers + output + input weight
     = ten slab jobs, two more than the batched launch holds: the last products sum their slabs at once) and residual_proj, at
     700 nodes -- above the 512 where the weight gradients split K over slabs.  Loss, every parameter gradient and the input
-    gradient against autograd through the restatement."""
+    gradient against autograd through the restatement.  hidden = 128 > max(in, out): the H x H lin gradient is then the largest
+    weight-gradient product -- the slab region was sized without it until round 4 (found by tools/fuzz_train.py: a fault)."""
     from neural_spectral_codec_amd.gnn.model import SpectralGNN
     n = 700
-    torch.manual_seed(6)
-    m = SpectralGNN(input_dim=in_dim, hidden_dim=64, output_dim=out_dim, n_layers=n_layers, dropout=0.0, residual=True, edge_dim=2)
+    # (fixed draws: a pre-activation of ~1e-8 that the kernels and torch round to different sides of a ReLU moves single-channel
+    # gradients by 1e-3 -- a tie, not an error; tools/fuzz_train.py re-draws the features to tell the two apart.  These draws have none.)
+    torch.manual_seed(6 if hidden == 64 else 21)
+    m = SpectralGNN(input_dim=in_dim, hidden_dim=hidden, output_dim=out_dim, n_layers=n_layers, dropout=0.0, residual=True, edge_dim=2)
     go.randomize_bn_stats(m, 7)
     assert (m.residual_proj is not None) == (in_dim != out_dim)
     m = m.to("cuda")

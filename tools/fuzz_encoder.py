@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak (not part of the test suite): many full-size random clouds through nsc_encode_clouds vs the C
 oracle -- raw and interpolated range images must be bit-identical, descriptors within 1e-6 relative.
-usage: fuzz_encoder.py [n_rounds] [clouds_per_round] [points_per_cloud]"""
+usage: fuzz_encoder.py [n_rounds] [clouds_per_round] [points_per_cloud] [config: 0-5 = the fixed sets below, -SEED = a random one]"""
 import os
 import sys
 import time
@@ -29,6 +29,16 @@ CFG = [dict(),
        dict(n_bins=37, alpha=1.3),
        dict(xyz_only=True)]
 cfg_id = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+if cfg_id < 0:
+    # a RANDOM parameter set from the range check_params accepts (seed = -cfg_id): projector rows 1-64, target rows 1-16
+    # (<= projector rows), 1-176 bins, any alpha, any field of view, either row arithmetic, (N,3) or (N,4) points
+    prng = np.random.default_rng(-cfg_id)
+    E_ = int(prng.integers(1, 65))
+    lo_ = float(prng.uniform(-60, 10))
+    CFG.append(dict(n_elevation=E_, target_elevation_bins=int(prng.integers(1, min(E_, 16) + 1)), n_bins=int(prng.integers(1, 177)),
+                    alpha=float(prng.uniform(0.3, 4.0)), elevation_range=(lo_, lo_ + float(prng.uniform(2, 80))),
+                    elev_float64=bool(prng.integers(0, 2)), xyz_only=bool(prng.integers(0, 2))))
+    cfg_id = len(CFG) - 1
 kw = dict(CFG[cfg_id])
 xyz_only = kw.pop("xyz_only", False)
 kw.setdefault("n_elevation", 16)

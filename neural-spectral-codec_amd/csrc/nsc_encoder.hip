@@ -1317,7 +1317,7 @@ const char *nsc_status_string(int s)
     switch (s) {
     case NSC_OK: return "ok";
     case NSC_EINVAL: return "invalid argument";
-    case NSC_EUNSUPPORTED: return "unsupported shape (n_azimuth must be 360, rows <= 64, target_rows <= 16, n_bins <= 176)";
+    case NSC_EUNSUPPORTED: return "unsupported shape or parameter for this entry point (limits: include/nsc.h; encoder: n_azimuth 360, rows <= 64, target_rows <= 16, n_bins <= 176; W1 retrieval: width <= 1024; wire format: width <= 4096)";
     case NSC_EWORKSPACE: return "workspace too small";
     case NSC_ELAUNCH: return "kernel launch failed";
     default: return "unknown status";

@@ -77,6 +77,11 @@ def _topk(dist: torch.Tensor, k: int):
     with torch.cuda.device(dist.device):
         st = L.nsc_topk_smallest(_lib.ptr(dist), q, n, k, _lib.ptr(idx), _lib.ptr(val), _lib.ptr(ws), nbytes,
                                  _lib.stream_ptr(dist.device))
+    if st == -2 and 0 < k <= n:
+        # beyond the selection kernel's range (k > 256: the reference's callers ask for 10-50, but `query(top_k=n)` is legal there,
+        # wasserstein.py:380): a stable device sort gives the same (value, index) order -- still on the device, no host copy
+        val, idx = torch.sort(dist, dim=1, stable=True)
+        return idx[:, :k].contiguous(), val[:, :k].contiguous()
     _lib.check(st, "nsc_topk_smallest")
     return idx, val
 

@@ -2,7 +2,7 @@
 """One-off soak (not part of the test suite): GPU hard-negative mining (TripletMiner, nsc_mine_triplets) on random looping
 tracks -- 1-3 sequences of 60-900 keyframes, descriptor widths 50 / 800, 1-3 triplets per anchor -- against
 oracle/miner_oracle.py: the same anchors produce triplets, the hard negative is the oracle's argmin-W1 candidate (or a candidate
-within 1e-5 of it: float32 near-ties), every positive lies in the oracle's candidate set.
+within 2e-4 of it -- W1 is a float32 sum over up to 800 CDF bins, ~1e-7 each: the bound tests/test_retrieval.py uses), every positive lies in the oracle's candidate set.
 usage: fuzz_miner.py [n_cases]"""
 import os
 import sys
@@ -53,10 +53,10 @@ for ci in range(n_cases):
             assert p in cand[a][0], f"case {ci}: positive of anchor {a} outside the candidate set"
             if n_ != cand[a][2]:                                 # a float32 near-tie of two candidates' W1 distances
                 dw = abs(mo.w1_numpy(desc[a], desc[n_]) - mo.w1_numpy(desc[a], desc[cand[a][2]]))
-                assert n_ in set(cand[a][1].tolist()) and dw <= 1e-5, f"case {ci}: negative of anchor {a}: {n_} vs {cand[a][2]} (dW1 {dw:.2e})"
+                assert n_ in set(cand[a][1].tolist()) and dw <= 2e-4, f"case {ci}: negative of anchor {a}: {n_} vs {cand[a][2]} (dW1 {dw:.2e})"
                 near += 1
             total += 1
     if ci % 10 == 9:
         print(f"{ci + 1} cases, {total} triplets, {near} near-ties ({time.time() - t0:.0f} s)", flush=True)
 print(f"TOTAL {n_cases} cases, {total} triplets: same anchors, every positive in the candidate set, hard negative = the oracle's argmin "
-      f"({near} float32 near-ties within 1e-5)")
+      f"({near} float32 near-ties within 2e-4)")

@@ -56,6 +56,13 @@ def test_gpu_distances_and_topk():
     assert idx.tolist() == G["top_idx"].tolist()
     assert np.allclose(dist, G["top_dist"], rtol=RTOL)
     assert r.database_size == 300 and r.database_hists.shape == (300, 800)
+    # top_k beyond the selection kernel's range (k > 256): the whole database in (distance, index) order, as the reference's
+    # argpartition + argsort would give it (wasserstein.py:372-384)
+    idx_all, dist_all = r.query(G["q"][1], top_k=300)
+    d = ro.batch(G["q"][1], G["db"])
+    o, dv = ro.topk(d, 300)
+    assert np.allclose(dist_all, dv, rtol=RTOL, atol=1e-5) and sorted(idx_all.tolist()) == list(range(300))
+    assert (np.abs(d[idx_all] - dv) <= RTOL * np.abs(dv) + 1e-5).all()
     r.clear_database()
     assert r.query(G["q"][0])[0].size == 0
 

@@ -1276,6 +1276,10 @@ struct EndPartials {
     ColPartJobs att;                                                // workgroups [0, n_att): (column block, row block, layer)
     int N, C, rows, nbx, R;
     unsigned n_att;
+    const float *ob_P;                                              // then the output bias: column sums of dOut (N, ob_C),
+    double *ob_part;                                                //   workgroups (column block, row block)
+    int ob_C, ob_nbx;
+    unsigned n_ob;
     EdgeTermArgs edge;                                              // then EDGE_BWD_WGS per layer
 };
 __global__ __launch_bounds__(256) void backward_end_partials_kernel(EndPartials p)
@@ -1284,8 +1288,12 @@ __global__ __launch_bounds__(256) void backward_end_partials_kernel(EndPartials 
     if (b < p.n_att) {
         const int bx = (int)(b % (unsigned)p.nbx), t = (int)(b / (unsigned)p.nbx), by = t % p.R, l = t / p.R;
         colreduce_partial_body(p.att.P[l], p.att.w[l], nullptr, nullptr, nullptr, p.N, p.C, p.rows, p.att.part[l], p.att.w2[l], bx, by);
-    } else {
+    } else if (b < p.n_att + p.n_ob) {
         b -= p.n_att;
+        colreduce_partial_body(p.ob_P, nullptr, nullptr, nullptr, nullptr, p.N, p.ob_C, p.rows, p.ob_part, nullptr,
+                               (int)(b % (unsigned)p.ob_nbx), (int)(b / (unsigned)p.ob_nbx));
+    } else {
+        b -= p.n_att + p.n_ob;
         edge_term_bwd_body(p.edge, (int)(b % EDGE_BWD_WGS), (int)(b / EDGE_BWD_WGS));
     }
 }
@@ -1788,13 +1796,10 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
     const int acc = cfg->accumulate_grads ? 1 : 0;
 
     // output_proj: out = h_L W_out^T + b (+ x)
-    {
-        double *ob = reinterpret_cast<double *>(b + w.colpart_ob);
-        hipLaunchKernelGGL(colreduce_partial_kernel, dim3((Dout + 63) / 64, Rn), dim3(256), 0, st, grad_out, static_cast<const float *>(nullptr),
-                           static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), static_cast<const float *>(nullptr),
-                           N, Dout, rows_n, ob, static_cast<const float *>(nullptr));
-        push_final(ob, Dout, ColFinal{0, N, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr, acc, 0, nullptr, nullptr, 0}, no_extra);
-    }
+    // (its column sums of dOut: with the other partial sums in the backward's second-to-last launch -- dOut is the caller's, nothing
+    // overwrites it)
+    double *ob = reinterpret_cast<double *>(b + w.colpart_ob);
+    push_final(ob, Dout, ColFinal{0, N, 0.f, 0.f, gr->out_b, nullptr, nullptr, nullptr, acc, 0, nullptr, nullptr, 0}, no_extra);
     gemm<true, true>(st, grad_out, Dout, F(w.h + w.nh * L), H, Dout, H, N, gr->out_w, H, nullptr, acc, splits, slabs, defer);
     float *dh = F(w.dh), *dh_prev = F(w.dh2);
     gemm<false, true>(st, grad_out, Dout, m->out_w, H, N, H, Dout, dh, H, nullptr, 0, 1, slabs);   // dh_L = dOut W_out
@@ -1894,8 +1899,9 @@ int nsc_gat_backward(const NscGatModel *m, const NscGraph *g, const float *x, co
         EndPartials pa = {};
         pa.att = attp; pa.N = N; pa.C = H; pa.rows = rows_n; pa.nbx = (H + 63) / 64; pa.R = Rn;
         pa.n_att = (unsigned)(pa.nbx * Rn * L);
+        pa.ob_P = grad_out; pa.ob_part = ob; pa.ob_C = Dout; pa.ob_nbx = (Dout + 63) / 64; pa.n_ob = (unsigned)(pa.ob_nbx * Rn);
         pa.edge = EdgeTermArgs{g->row_ptr, g->eid, g->tgt, g->loop_attr, edge_attr, F(w.draw), (long long)(w.nz / 4), N, m->edge_dim, ep};
-        hipLaunchKernelGGL(backward_end_partials_kernel, dim3(pa.n_att + (any_edge ? (unsigned)(EDGE_BWD_WGS * L) : 0u)), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(backward_end_partials_kernel, dim3(pa.n_att + pa.n_ob + (any_edge ? (unsigned)(EDGE_BWD_WGS * L) : 0u)), dim3(256), 0, st, pa);
         EndFinals fa = {};
         fa.fin = fin; fa.nbx = (std::max(H, Dout) + 63) / 64;
         fa.n_fin = (unsigned)(fa.nbx * fin.n); fa.n_edge = any_edge ? (unsigned)L : 0u;

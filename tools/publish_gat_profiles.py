@@ -13,11 +13,11 @@ import sys
 d, T = sys.argv[1], sys.argv[2]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "profiles")
-shutil.copy(glob.glob(f"{d}/trace/*/*kernel_stats.csv")[0], f"{P}/{T}_gat_n4541_kernel_stats.csv")
-shutil.copy(glob.glob(f"{d}/trace1024/*/*kernel_stats.csv")[0], f"{P}/{T}_gat_n1024_kernel_stats.csv")
+shutil.copy(max(glob.glob(f"{d}/trace/*/*kernel_stats.csv"), key=os.path.getmtime), f"{P}/{T}_gat_n4541_kernel_stats.csv")
+shutil.copy(max(glob.glob(f"{d}/trace1024/*/*kernel_stats.csv"), key=os.path.getmtime), f"{P}/{T}_gat_n1024_kernel_stats.csv")
 acc = collections.defaultdict(list)
 for sub in ("pmc1", "pmc2"):
-    for r in csv.DictReader(open(glob.glob(f"{d}/{sub}/*/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open(max(glob.glob(f"{d}/{sub}/*/*counter_collection.csv"), key=os.path.getmtime))):
         name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
         if "gemm" in name or "aggregate" in name or "banded" in name:
             acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))

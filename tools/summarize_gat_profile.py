@@ -2,6 +2,7 @@
 """rocprofv3 output of tools/gat_profile.sh (kernel trace + two PMC passes of the config-3 GAT forward) -> markdown.
 usage: summarize_gat_profile.py gpurun_out/<tag> > profiles/<round>_gat_n4541_rocprof.md"""
 import collections
+import os
 import csv
 import glob
 import re
@@ -30,7 +31,7 @@ def key(name):
     return None
 
 
-stats = list(csv.DictReader(open(glob.glob(d + "/trace/*/*kernel_stats.csv")[0])))
+stats = list(csv.DictReader(open(max(glob.glob(d + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime))))
 dur = {}
 print("## Kernel durations (rocprofv3 --kernel-trace --stats, `tools/gat_workload.py 4541 50`)\n")
 print("| kernel | role | calls | avg us | min us | GFLOP | TFLOP/s (avg) | % of 157.3 TF |\n|---|---|---|---|---|---|---|---|")

@@ -15,7 +15,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_kernel(sub, counter):
-    rows = csv.DictReader(open(glob.glob(f"{d}/{sub}/*/*counter_collection.csv")[0]))
+    rows = csv.DictReader(open(max(glob.glob(f"{d}/{sub}/*/*counter_collection.csv"), key=os.path.getmtime)))
     acc = defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == counter:

@@ -3,6 +3,7 @@
 streams.  usage: summarize_profile.py gpurun_out/<tag>/bench_trace [steps warmup] > ...
 bench.py (N = 1, --no-extras) launches the encoder: spin-up max(40 - W, 1) + W warmup + K timed + 20 alone + 24 alone on two
 overlapping streams; the timed region is located by those counts."""
+import os
 import csv
 import glob
 import sys
@@ -11,12 +12,12 @@ d = sys.argv[1]
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 SOLO, SOLO2 = 20, 24
-stats = list(csv.DictReader(open(glob.glob(d + "/*/*kernel_stats.csv")[0])))
+stats = list(csv.DictReader(open(max(glob.glob(d + "/*/*kernel_stats.csv"), key=os.path.getmtime))))
 print("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
 for r in stats[:22]:
     print(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
           f"{float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
-rows = list(csv.DictReader(open(glob.glob(d + "/*/*kernel_trace.csv")[0])))
+rows = list(csv.DictReader(open(max(glob.glob(d + "/*/*kernel_trace.csv"), key=os.path.getmtime))))
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 enc_all = [k for k in ks if ('encode_fused' in k[2] or 'encode_fast' in k[2])]
 if len(enc_all) >= K + SOLO + SOLO2:

@@ -1,5 +1,6 @@
+import os
 import csv,glob,re,sys
-f=glob.glob(sys.argv[1]+"/*/*kernel_stats.csv")[0]
+f=max(glob.glob(sys.argv[1]+"/*/*kernel_stats.csv"), key=os.path.getmtime)
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r["TotalDurationNs"]) for r in rows); n=sum(int(r["Calls"]) for r in rows)
 print(n, round(tot/1e6,2))
